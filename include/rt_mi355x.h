@@ -1,0 +1,262 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) path-tracing library.
+ *
+ * The reference program (ray-tracer/main.odin) has no FFI of its own: its hot
+ * path is the Odin procedure `render_region` (main.odin:510-591) that `main`
+ * calls at main.odin:840-844 and the benchmark calls at main_test.odin:27-31.
+ * This header declares the C entry points an Odin `foreign import` block binds
+ * in place of those calls.  Every struct below has the field order, field
+ * types and therefore the byte layout of the Odin struct it names, so the Odin
+ * host can pass `raw_data(world.spheres)` etc. without conversion.
+ *
+ * All pointers are owned by the caller.  Nothing is retained after a call
+ * returns except what an explicit handle (rt_world) owns.  No function throws
+ * across the boundary: every int32_t return is RT_OK or a negative RT_ERR_*
+ * and rt_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------- */
+#define RT_OK 0
+#define RT_ERR_INVALID_ARGUMENT (-1) /* null pointer, bad size, bad rect, bad option value      */
+#define RT_ERR_INVALID_SCENE (-2)    /* material_index out of range, fuzz outside [0,1], r == 0 */
+#define RT_ERR_DEVICE (-3)           /* a HIP call failed (no GPU, out of memory, launch error) */
+#define RT_ERR_UNSUPPORTED (-4)      /* a documented limit was exceeded                          */
+#define RT_ERR_BUFFER_TOO_SMALL (-5) /* caller-provided capacity is insufficient                 */
+
+/* ---- data that crosses the boundary (layouts == the Odin structs) ------ */
+
+/* v3 :: [3]f64                                             main.odin:19   */
+typedef struct { double x, y, z; } rt_v3;
+
+/* sphere :: struct {center: v3, radius: f64, material_index: i64}   main.odin:487-491 (40 B) */
+typedef struct { rt_v3 center; double radius; int64_t material_index; } rt_sphere;
+
+/* material_type :: enum i64 {lambertian, metallic, dielectric}      main.odin:268-272 */
+#define RT_MATERIAL_LAMBERTIAN 0
+#define RT_MATERIAL_METALLIC 1
+#define RT_MATERIAL_DIELECTRIC 2
+
+/* material :: struct {type: material_type, data: {albedo: v3, param1: f64}}
+ * param1 = fuzz for metallic, refractive index for dielectric       main.odin:274-289 (40 B) */
+typedef struct { int64_t type; rt_v3 albedo; double param1; } rt_material;
+
+/* camera_render_data                                        main.odin:440-448 (168 B)
+ * depth_of_field_angle is in turns (1 turn = 2*pi rad, main.odin:21-23). */
+typedef struct {
+    rt_v3 position;
+    rt_v3 pixel_delta_u, pixel_delta_v;
+    rt_v3 view_plane_top_left_pixel_center;
+    rt_v3 dof_disk_u, dof_disk_v;
+    double depth_of_field_angle;
+    int64_t samples_per_pixel;
+    int64_t max_ray_bounces;
+} rt_camera_render_data;
+
+/* camera_settings                                           main.odin:425-438 (176 B)
+ * image_size is v2 ([2]f64); vfov and depth_of_field_angle are in turns. */
+typedef struct {
+    rt_v3 position, right, up, forward;
+    double aspect_ratio;
+    double image_size_x, image_size_y;
+    double focus_distance;
+    double vfov;
+    double depth_of_field_angle;
+    int64_t samples_per_pixel;
+    int64_t max_ray_bounces;
+} rt_camera_settings;
+
+/* rect: half-open pixel rectangle                            main.odin:503-508 */
+typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect;
+
+/* ---- options ------------------------------------------------------------ */
+
+/* arithmetic the kernel computes in */
+#define RT_PRECISION_F32 0         /* f32, fused multiply-adds in the ray/sphere test (throughput path)      */
+#define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
+#define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
+
+/* how a wave obtains the (wave-uniform) sphere records in the closest-hit scan */
+#define RT_FETCH_AUTO 0
+#define RT_FETCH_SCALAR 1 /* scalar-cache loads into SGPRs                              */
+#define RT_FETCH_LDS 2    /* SoA records staged once per workgroup into LDS, broadcast  */
+
+#define RT_RNG_STOCHASTIC 0    /* seed is mixed with a per-process call counter and the clock */
+#define RT_RNG_DETERMINISTIC 1 /* the counter RNG is keyed by `seed` alone: same inputs, same image */
+
+/* indices into the optional stats array */
+#define RT_STAT_SEGMENTS 0     /* ray segments traced = executed iterations of the bounce loop main.odin:535 */
+#define RT_STAT_SPHERE_TESTS 1 /* segments * n_spheres = calls of ray_sphere_intersection main.odin:541   */
+#define RT_STAT_KERNEL_NS 2    /* device time of the render kernels of this call, from HIP events          */
+#define RT_STAT_SAMPLES 3      /* camera rays started                                                       */
+#define RT_STATS_COUNT 8
+
+typedef struct {
+    uint64_t seed;
+    int32_t rng_mode;      /* RT_RNG_*                                                         */
+    int32_t precision;     /* RT_PRECISION_*                                                   */
+    int32_t sphere_fetch;  /* RT_FETCH_*                                                       */
+    int32_t device;        /* HIP device ordinal, or -1 for the calling thread's current one  */
+    int32_t device_count;  /* rt_render_region only: spread 8-row strips over this many GPUs
+                              starting at `device` (0 and 1 both mean one GPU)                */
+    int32_t sample_chunks; /* split samples_per_pixel over this many waves per tile; 0 = auto */
+    rt_v3 *linear_out;     /* optional, width*height: pre-gamma sample means of region pixels  */
+    uint64_t *stats;       /* optional, RT_STATS_COUNT counters for this call                  */
+} rt_options;
+
+/* ---- library ------------------------------------------------------------ */
+
+const char *rt_version(void);
+/* message of the calling thread's last failing call; never NULL */
+const char *rt_last_error(void);
+/* number of HIP devices visible, or a negative RT_ERR_DEVICE */
+int32_t rt_device_count(void);
+void rt_options_default(rt_options *opts);
+
+/* ---- the drop-in entry points -------------------------------------------- */
+
+/*
+ * Replaces render_region (main.odin:510-591; call sites main.odin:841,
+ * main_test.odin:28 and, per tile, main.odin:609).
+ *
+ * For every pixel (u, v) of `region` traces cam->samples_per_pixel paths of
+ * at most cam->max_ray_bounces + 1 segments through the sphere list and
+ * writes the gamma-2 colour (sqrt of the sample mean, main.odin:577-586) to
+ * image_data[u + v * width].  Pixels outside `region` are not touched.
+ * Host pointers in, host pointers out; synchronous; safe to call from several
+ * threads (calls are serialised per device).
+ * opts may be NULL (f32, deterministic, seed 0, current device).
+ */
+int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_rect region,
+                         const rt_camera_render_data *cam,
+                         const rt_sphere *spheres, int64_t n_spheres,
+                         const rt_material *materials, int64_t n_materials,
+                         const rt_options *opts);
+
+/*
+ * Replaces render_tiled (main.odin:635-685; call sites main.odin:843,
+ * main_test.odin:30): renders the whole image.  The reference cuts the image
+ * into 2x2-pixel CPU tasks; here the GPU grid of 8x8-pixel wave tiles is the
+ * tiling, so this is rt_render_region over {0, 0, width, height}.
+ */
+int32_t rt_render_tiled(rt_v3 *image_data, int64_t width, int64_t height,
+                        const rt_camera_render_data *cam,
+                        const rt_sphere *spheres, int64_t n_spheres,
+                        const rt_material *materials, int64_t n_materials,
+                        const rt_options *opts);
+
+/* ---- device-resident form of the same path -------------------------------- */
+/*
+ * The reference keeps `world` (main.odin:493-496) alive across the 100
+ * render_region calls of its benchmark (main_test.odin:13-32).  rt_world is
+ * that object on the GPU: validated, converted from AoS f64 to SoA f32 + f64
+ * and uploaded once.
+ */
+typedef struct rt_world_s rt_world;
+
+int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres,
+                        const rt_material *materials, int64_t n_materials,
+                        int32_t device, rt_world **out);
+int32_t rt_world_destroy(rt_world *world);
+
+/*
+ * The loops of render_region up to and including `pixel_color += sample_color`
+ * (main.odin:513-576) for a subset of the work, with everything in device
+ * memory:
+ *   pixels : the pixels of `region` whose 8-row strip s = (v - region.min_y) /
+ *            strip_rows satisfies s % strip_count == strip_index
+ *            (strip_count 1 = the whole region; strip_rows a multiple of 8);
+ *   samples: the global sample indices [sample_begin, sample_begin+sample_count).
+ * d_accum is a device buffer of width*height*3 elements (float for the F32
+ * precisions, double for F64) indexed [(u + v*width)*3 + channel]; the call
+ * overwrites the entries of its pixels with the SUM of its samples' colours.
+ * cam->samples_per_pixel is ignored here.  d_stats is NULL or a device array
+ * of RT_STATS_COUNT u64 the kernel adds RT_STAT_SEGMENTS / RT_STAT_SAMPLES
+ * into.  `stream` is a hipStream_t (NULL = the default stream); the call is
+ * asynchronous with respect to the host.  Because the RNG is keyed by the
+ * global pixel index and the global sample index, any partition of pixels or
+ * samples over calls, streams or GPUs traces exactly the same paths.
+ */
+int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam,
+                             int64_t width, int64_t height, rt_rect region,
+                             int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                             int64_t sample_begin, int64_t sample_count,
+                             uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                             int32_t sample_chunks,
+                             void *d_accum, uint64_t *d_stats, void *stream);
+
+/*
+ * The tail of the pixel loop (main.odin:577-586) on the device: for the
+ * pixels selected as above, mean = accum / total_samples, and
+ * d_image[u + v*width] = sqrt(mean) per channel (device rt_v3 array);
+ * d_linear, if not NULL, receives the mean itself.
+ */
+int32_t rt_finalize(rt_world *world, const void *d_accum, int32_t precision,
+                    int64_t width, int64_t height, rt_rect region,
+                    int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                    int64_t total_samples, rt_v3 *d_image, rt_v3 *d_linear, void *stream);
+
+/* device time in ns of the render kernels launched for `world` by the last
+ * rt_render_accumulate on it (blocks until they finish); <0 on error */
+int64_t rt_world_last_kernel_ns(rt_world *world);
+
+/* ---- host-side helpers the callers of the path use ------------------------ */
+
+/* lookat (main.odin:65-71) */
+void rt_lookat(rt_v3 position, rt_v3 target, rt_v3 axis_up, rt_v3 *right, rt_v3 *up, rt_v3 *forward);
+/* calculate_camera_render_data (main.odin:450-485) */
+void rt_calculate_camera_render_data(const rt_camera_settings *settings, rt_camera_render_data *out);
+
+/*
+ * Scene builders.  spheres/materials are caller arrays of *n_spheres /
+ * *n_materials capacity; on return the counts hold the number written
+ * (RT_ERR_BUFFER_TOO_SMALL leaves the required counts there).
+ *   dev   : build_dev_scene (main.odin:687-737), verbatim data.
+ *   two   : ground + centre lambertian spheres, camera at the origin, vfov 90 deg.
+ *   final : the generation rule of build_final_scene (main.odin:739-789).  The
+ *           reference draws from Odin's global generator after rand.reset(1);
+ *           that stream is not reproducible outside Odin, so the draws come
+ *           from splitmix64(seed) in the same order.
+ *   stress: ground + (n-1) small spheres on a 60x60 field, same material mix.
+ * image_width sets image_size (height = width / aspect_ratio, as main.odin:729).
+ */
+int32_t rt_build_dev_scene(int64_t image_width, rt_camera_settings *settings,
+                           rt_sphere *spheres, int64_t *n_spheres,
+                           rt_material *materials, int64_t *n_materials);
+int32_t rt_build_two_sphere_scene(int64_t image_width, rt_camera_settings *settings,
+                                  rt_sphere *spheres, int64_t *n_spheres,
+                                  rt_material *materials, int64_t *n_materials);
+int32_t rt_build_final_scene(uint64_t seed, int64_t image_width, rt_camera_settings *settings,
+                             rt_sphere *spheres, int64_t *n_spheres,
+                             rt_material *materials, int64_t *n_materials);
+int32_t rt_build_stress_scene(uint64_t seed, int64_t total_spheres, int64_t image_width,
+                              rt_camera_settings *settings,
+                              rt_sphere *spheres, int64_t *n_spheres,
+                              rt_material *materials, int64_t *n_materials);
+
+/*
+ * serialize_ppm (main.odin:791-824): "P3\n{w} {h}\n255\n" then 12 bytes per
+ * pixel, each channel u8(256 * min(x, 0.999)) right-aligned in 3 columns.
+ * Returns the number of bytes the image needs; writes them if capacity allows
+ * (dst may be NULL to query).  No terminating NUL is written.
+ */
+int64_t rt_serialize_ppm(const rt_v3 *image_data, int64_t width, int64_t height,
+                         char *dst, int64_t capacity);
+/* the quantiser of main.odin:812-814 alone: rgb8 gets width*height*3 bytes */
+int32_t rt_quantize_rgb8(const rt_v3 *image_data, int64_t n_pixels, uint8_t *rgb8);
+
+/* the counter RNG the kernels use: u32 draw for (seed, pixel, sample, bounce, draw) */
+uint32_t rt_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t draw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,554 @@
+/*
+ * rt_oracle.cpp -- CPU restatement of the reference's per-pixel path-tracing loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library links, loads or calls this
+ * file; it exists so that tests, the smoke check and the benchmark's cpu_baseline leg
+ * have an independent statement of what the reference computes.
+ *
+ * PARITY UNPINNED: the reference (ray-tracer/main.odin, one Odin file) holds no golden
+ * vectors, no known-answer tests and no rendered image (out/image.ppm is absent from the
+ * checkout), and no Odin compiler exists in this environment, so this restatement cannot
+ * be checked against outputs of the reference itself.  It is instead cross-checked
+ * against a second, independently written Python restatement (tests/pyref.py) and against
+ * closed-form results.
+ *
+ * The random numbers do not come from Odin's core:math/rand (third-party, unpinned, its
+ * default generator changed between Odin releases) but from the counter RNG defined below,
+ * injected at exactly the reference's call sites and in the reference's draw order.
+ *
+ * Real = double, FMA = false : the reference's arithmetic as written (v3 :: [3]f64,
+ *                              main.odin:19; LLVM does not contract a*b+c without fast-math).
+ * Real = float,  FMA = false : the same operation order in f32.
+ * Real = float,  FMA = true  : as above, but the three dot-product chains of the
+ *                              ray/sphere test use fused multiply-adds -- the arithmetic
+ *                              of the GPU throughput kernel.
+ */
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "../include/rt_mi355x.h" /* struct layouts only */
+
+namespace {
+
+/* ---------------------------------------------------------------- counter RNG
+ * draw(seed, pixel, sample, bounce, j):
+ *   K0 = mix(lo32(seed) ^ 0x9e3779b9)      K1 = mix(hi32(seed) ^ K0 ^ 0x85ebca6b)
+ *   kp = mix(K0 ^ pixel)                   wp = mix(K1 + pixel)
+ *   ks = mix(kp + 0x9e3779b9 * (sample+1))
+ *   kb = mix(ks ^ (0x85ebca6b * (bounce+1)))
+ *   u  = mix(kb + 0xc2b2ae35 * (j+1)) ^ wp
+ * bounce 0 = the camera draws of a sample, bounce k+1 = the scatter draws at segment k.
+ * uniform in [0,1): (u >> 8) * 2^-24 -- exact in f32 and f64, so both precisions see
+ * the same random numbers.
+ */
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+struct seed_keys { uint32_t k0, k1; };
+inline seed_keys keys_from_seed(uint64_t seed) {
+    seed_keys k;
+    k.k0 = mix32(static_cast<uint32_t>(seed) ^ 0x9e3779b9u);
+    k.k1 = mix32(static_cast<uint32_t>(seed >> 32) ^ k.k0 ^ 0x85ebca6bu);
+    return k;
+}
+struct draw_stream { /* the draws of one (pixel, sample, bounce) */
+    uint32_t kb, wp, j;
+    draw_stream(seed_keys k, uint32_t pixel, uint32_t sample, uint32_t bounce) {
+        uint32_t kp = mix32(k.k0 ^ pixel);
+        wp = mix32(k.k1 + pixel);
+        uint32_t ks = mix32(kp + 0x9e3779b9u * (sample + 1u));
+        kb = mix32(ks ^ (0x85ebca6bu * (bounce + 1u)));
+        j = 0;
+    }
+    uint32_t next_u32() { ++j; return mix32(kb + 0xc2b2ae35u * j) ^ wp; }
+    template <class Real> Real next() { /* rand.float64(): uniform [0,1) */
+        return static_cast<Real>(next_u32() >> 8) * static_cast<Real>(1.0 / 16777216.0);
+    }
+    /* rand.float64_range(lo, hi) of Odin core:math/rand: (hi-lo)*float64() + lo, and a
+     * result that rounds up to hi is pulled back below it. */
+    template <class Real> Real range(Real lo, Real hi) {
+        Real val = (hi - lo) * next<Real>() + lo;
+        if (val >= hi) val = std::max(lo, hi * (Real(1) - std::numeric_limits<Real>::epsilon()));
+        return val;
+    }
+};
+
+/* rejection loops are unbounded in the reference (main.odin:196, :216); with this RNG
+ * 64 straight rejections have probability < 1e-20, after which the last candidate is
+ * taken so that every loop provably ends. */
+constexpr int REJECTION_CAP = 64;
+
+/* ---------------------------------------------------------------- linalg  main.odin:19-63 */
+template <class Real> struct vec3 { Real x, y, z; };
+template <class Real> inline vec3<Real> operator+(vec3<Real> a, vec3<Real> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class Real> inline vec3<Real> operator-(vec3<Real> a, vec3<Real> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class Real> inline vec3<Real> operator-(vec3<Real> a) { return {-a.x, -a.y, -a.z}; }
+template <class Real> inline vec3<Real> operator*(vec3<Real> a, vec3<Real> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class Real> inline vec3<Real> operator*(Real s, vec3<Real> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class Real> inline vec3<Real> operator*(vec3<Real> a, Real s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class Real> inline vec3<Real> operator/(vec3<Real> a, Real s) { return {a.x / s, a.y / s, a.z / s}; }
+
+/* dot  main.odin:28-30: a.x*b.x + a.y*b.y + a.z*b.z, left to right */
+template <class Real> inline Real dot(vec3<Real> a, vec3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* cross  main.odin:32-38 */
+template <class Real> inline vec3<Real> cross(vec3<Real> a, vec3<Real> b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+/* magnitude_squared / magnitude / normalize  main.odin:40-50 */
+template <class Real> inline Real magnitude_squared(vec3<Real> v) { return dot(v, v); }
+template <class Real> inline Real magnitude(vec3<Real> v) { return std::sqrt(magnitude_squared(v)); }
+template <class Real> inline vec3<Real> normalize(vec3<Real> v) { return v / magnitude(v); }
+/* is_near_zero  main.odin:52-57 */
+template <class Real> inline bool is_near_zero(vec3<Real> v) {
+    const Real EPSILON = Real(1e-8);
+    return std::fabs(v.x) <= EPSILON && std::fabs(v.y) <= EPSILON && std::fabs(v.z) <= EPSILON;
+}
+
+/* ---------------------------------------------------------------- optics  main.odin:77-176 */
+/* reflect  main.odin:77-80: vec - 2*dot(vec, normal)*normal */
+template <class Real> inline vec3<Real> reflect(vec3<Real> v, vec3<Real> n) { return v - (Real(2) * dot(v, n)) * n; }
+/* reflectance_at_normal_incidence  main.odin:111-115 */
+template <class Real> inline Real reflectance_at_normal_incidence(Real rel) {
+    Real r0 = (Real(1) - rel) / (Real(1) + rel);
+    r0 *= r0;
+    return r0;
+}
+/* reflectance_schlick_approximation  main.odin:119-122: r0 + (1-r0)*a*a*a*a*a */
+template <class Real> inline Real reflectance_schlick_approximation(Real cos_i, Real r0) {
+    Real a = Real(1) - cos_i;
+    return r0 + (Real(1) - r0) * a * a * a * a * a;
+}
+/* refract_with_relative_refractive_index, arithmetic only  main.odin:168-173 */
+template <class Real> inline vec3<Real> refract(vec3<Real> v, vec3<Real> n, Real rel) {
+    Real cos_theta = std::min(dot(-v, n), Real(1));
+    vec3<Real> perp = rel * (v + cos_theta * n);
+    vec3<Real> par = (-std::sqrt(std::max(Real(1) - magnitude_squared(perp), Real(0)))) * n;
+    return perp + par;
+}
+
+/* ---------------------------------------------------------------- random  main.odin:181-223 */
+/* random_unit_vector  main.odin:194-203 (3 draws per candidate: x, y, z) */
+template <class Real> inline vec3<Real> random_unit_vector(draw_stream &g) {
+    const Real hi = Real(1) + Real(DBL_EPSILON); /* 1 + math.F64_EPSILON: main.odin:197 */
+    vec3<Real> p{};
+    Real lsq = 0;
+    for (int it = 0; it < REJECTION_CAP; ++it) {
+        p.x = g.range<Real>(Real(-1), hi);
+        p.y = g.range<Real>(Real(-1), hi);
+        p.z = g.range<Real>(Real(-1), hi);
+        lsq = magnitude_squared(p);
+        if (Real(0) < lsq && lsq <= Real(1)) break;
+    }
+    return p / std::sqrt(lsq);
+}
+/* random_point_on_disk  main.odin:214-223 (2 draws per candidate; z = 0) */
+template <class Real> inline vec3<Real> random_point_on_disk(draw_stream &g) {
+    const Real hi = Real(1) + Real(DBL_EPSILON);
+    vec3<Real> p{};
+    for (int it = 0; it < REJECTION_CAP; ++it) {
+        p.x = g.range<Real>(Real(-1), hi);
+        p.y = g.range<Real>(Real(-1), hi);
+        p.z = Real(0);
+        if (magnitude_squared(p) <= Real(1)) break;
+    }
+    return p;
+}
+
+/* ---------------------------------------------------------------- raycast  main.odin:228-263 */
+template <class Real> struct ray_t { vec3<Real> origin, direction; };
+template <class Real> struct hit_record { vec3<Real> p, normal; bool front_face; };
+
+inline float fused(float a, float b, float c) { return std::fmaf(a, b, c); }
+inline double fused(double a, double b, double c) { return std::fma(a, b, c); }
+
+/* ray_sphere_intersection  main.odin:240-263.  returns t in [t_min, t_max) or t_max. */
+template <class Real, bool FMA>
+inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real radius, Real t_min, Real t_max) {
+    Real t = t_max;
+    vec3<Real> oc = c - r.origin;
+    Real a, h, cc, disc;
+    if (FMA) {
+        const vec3<Real> d = r.direction;
+        a = magnitude_squared(d);
+        h = fused(d.z, oc.z, fused(d.y, oc.y, d.x * oc.x));
+        cc = fused(oc.z, oc.z, fused(oc.y, oc.y, fused(oc.x, oc.x, -(radius * radius))));
+        disc = fused(h, h, -(a * cc));
+    } else {
+        a = magnitude_squared(r.direction);
+        h = dot(r.direction, oc);
+        cc = magnitude_squared(oc) - radius * radius;
+        disc = h * h - a * cc;
+    }
+    if (disc < 0) return t;
+    Real sqrtd = std::sqrt(disc);
+    Real root = (h - sqrtd) / a;
+    if (root < t_min || t_max <= root) {
+        root = (h + sqrtd) / a;
+        if (root < t_min || t_max <= root) return t;
+    }
+    t = root;
+    return t;
+}
+
+/* ---------------------------------------------------------------- materials  main.odin:268-410 */
+template <class Real> struct material_t { int64_t type; vec3<Real> albedo; Real param1; };
+
+template <class Real> struct scatter_result { ray_t<Real> ray_out; vec3<Real> attenuation; bool ok; };
+
+/* lambertian_proc  main.odin:292-312 */
+template <class Real>
+inline scatter_result<Real> lambertian_proc(const material_t<Real> &m, const ray_t<Real> &, const hit_record<Real> &hit, draw_stream &g) {
+    vec3<Real> dir = hit.normal + random_unit_vector<Real>(g);
+    if (is_near_zero(dir)) dir = hit.normal;
+    return {{hit.p, dir}, m.albedo, true};
+}
+/* metallic_proc, USE_METAL_FRESNEL = false branch  main.odin:315-323, :348-353 */
+template <class Real>
+inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
+    Real fuzz = m.param1;
+    vec3<Real> dir = normalize(reflect(ray_in.direction, hit.normal));
+    dir = dir + fuzz * random_unit_vector<Real>(g);
+    return {{hit.p, dir}, m.albedo, dot(dir, hit.normal) > Real(0)};
+}
+/* dielectric_proc  main.odin:356-400 */
+template <class Real>
+inline scatter_result<Real> dielectric_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
+    Real ri = m.param1;
+    Real src = ri >= Real(1) ? Real(1) : Real(1) / ri;
+    Real dst = ri >= Real(1) ? ri : Real(1);
+    if (!hit.front_face) std::swap(src, dst);
+    Real rel = src / dst;
+    vec3<Real> unit = normalize(ray_in.direction);
+    Real cos_theta = dot(-unit, hit.normal);
+    cos_theta = std::min(cos_theta, Real(1));
+    Real sin2 = Real(1) - cos_theta * cos_theta;
+    bool must_reflect = (rel * rel * sin2) > Real(1);
+    vec3<Real> dir;
+    /* `||` short-circuits: the uniform is drawn only when !must_reflect (main.odin:390) */
+    if (must_reflect || reflectance_schlick_approximation(cos_theta, reflectance_at_normal_incidence(rel)) > g.next<Real>())
+        dir = reflect(unit, hit.normal);
+    else
+        dir = refract(unit, hit.normal, rel);
+    return {{hit.p, dir}, {Real(1), Real(1), Real(1)}, true};
+}
+/* material_scatter  main.odin:403-410 */
+template <class Real>
+inline scatter_result<Real> material_scatter(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
+    switch (m.type) {
+    case RT_MATERIAL_LAMBERTIAN: return lambertian_proc(m, ray_in, hit, g);
+    case RT_MATERIAL_METALLIC: return metallic_proc(m, ray_in, hit, g);
+    default: return dielectric_proc(m, ray_in, hit, g);
+    }
+}
+
+/* background_color  main.odin:412-418; math.lerp(a, b, t) = a*(1-t) + b*t */
+template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
+    vec3<Real> a{Real(1), Real(1), Real(1)};
+    vec3<Real> b{Real(0.5), Real(0.7), Real(1.0)};
+    Real t = Real(0.5) * (r.direction.y + Real(1));
+    return a * (Real(1) - t) + b * t;
+}
+
+/* ---------------------------------------------------------------- the world in Real */
+template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; };
+template <class Real> struct camera_t {
+    vec3<Real> position, du, dv, top_left, dof_u, dof_v;
+    Real dof_angle;
+};
+template <class Real> inline vec3<Real> cvt(const rt_v3 &v) { return {static_cast<Real>(v.x), static_cast<Real>(v.y), static_cast<Real>(v.z)}; }
+
+template <class Real> struct scene_t {
+    std::vector<sphere_t<Real>> spheres;
+    std::vector<material_t<Real>> materials;
+    camera_t<Real> cam;
+    int64_t max_ray_bounces;
+    scene_t(const rt_camera_render_data *c, const rt_sphere *s, int64_t ns, const rt_material *m, int64_t nm) {
+        spheres.resize(ns);
+        for (int64_t i = 0; i < ns; ++i) spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index};
+        materials.resize(nm);
+        for (int64_t i = 0; i < nm; ++i) materials[i] = {m[i].type, cvt<Real>(m[i].albedo), static_cast<Real>(m[i].param1)};
+        cam = {cvt<Real>(c->position), cvt<Real>(c->pixel_delta_u), cvt<Real>(c->pixel_delta_v),
+               cvt<Real>(c->view_plane_top_left_pixel_center), cvt<Real>(c->dof_disk_u), cvt<Real>(c->dof_disk_v),
+               static_cast<Real>(c->depth_of_field_angle)};
+        max_ray_bounces = c->max_ray_bounces;
+    }
+};
+
+/* one sample of one pixel: main.odin:518-575.  returns sample_color; adds executed
+ * bounce-loop iterations to *segments. */
+template <class Real, bool FMA>
+inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t u, int64_t v, int64_t width, uint32_t sample, uint64_t *segments) {
+    const camera_t<Real> &cam = sc.cam;
+    const uint32_t pixel = static_cast<uint32_t>(u + v * width);
+    draw_stream cg(keys, pixel, sample, 0);
+    /* random_v2_range(-0.5, 0.5)  main.odin:519, :190-192 */
+    Real ox = cg.range<Real>(Real(-0.5), Real(0.5));
+    Real oy = cg.range<Real>(Real(-0.5), Real(0.5));
+    vec3<Real> pixel_sample_position = cam.top_left + (static_cast<Real>(u) + ox) * cam.du + (static_cast<Real>(v) + oy) * cam.dv;
+    vec3<Real> ray_origin = cam.position;
+    if (cam.dof_angle > Real(0)) {
+        vec3<Real> dof_sample = random_point_on_disk<Real>(cg);
+        ray_origin = ray_origin + ((dof_sample.x * cam.dof_u) + (dof_sample.y * cam.dof_v));
+    }
+    ray_t<Real> ray{ray_origin, pixel_sample_position - ray_origin};
+    vec3<Real> sample_color{Real(1), Real(1), Real(1)};
+    const int64_t n = static_cast<int64_t>(sc.spheres.size());
+    for (int64_t bounce = 0; bounce <= sc.max_ray_bounces; ++bounce) { /* 0..=max  main.odin:535 */
+        ++*segments;
+        Real closest_t = std::numeric_limits<Real>::max();
+        int64_t hit_index = -1;
+        const Real SHADOW_ACNE_RAY_OFFSET = Real(0.001);
+        for (int64_t i = 0; i < n; ++i) {
+            Real t = ray_sphere_intersection<Real, FMA>(ray, sc.spheres[i].center, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
+            if (t < closest_t) { closest_t = t; hit_index = i; }
+        }
+        if (hit_index >= 0) {
+            const sphere_t<Real> &sp = sc.spheres[hit_index];
+            const material_t<Real> &mat = sc.materials[sp.material_index];
+            hit_record<Real> hit;
+            hit.p = ray.origin + closest_t * ray.direction;
+            hit.normal = (hit.p - sp.center) / sp.radius;
+            hit.front_face = dot(ray.direction, hit.normal) < Real(0);
+            hit.normal = hit.front_face ? hit.normal : -hit.normal;
+            draw_stream sg(keys, pixel, sample, static_cast<uint32_t>(bounce) + 1u);
+            scatter_result<Real> s = material_scatter(mat, ray, hit, sg);
+            if (s.ok) {
+                ray = s.ray_out;
+                sample_color = sample_color * s.attenuation;
+            } else {
+                sample_color = {Real(0), Real(0), Real(0)};
+                break;
+            }
+        } else {
+            ray.direction = normalize(ray.direction);
+            sample_color = sample_color * background_color(ray);
+            break;
+        }
+    }
+    return sample_color;
+}
+
+struct render_args {
+    int64_t width, height;
+    rt_rect region;
+    const rt_camera_render_data *cam;
+    const rt_sphere *spheres; int64_t n_spheres;
+    const rt_material *materials; int64_t n_materials;
+    uint64_t seed;
+    int64_t sample_begin, sample_count, sample_chunks;
+    double *image, *linear, *accum;
+    uint64_t *stats;
+    int32_t threads;
+};
+
+/* render_region  main.odin:510-591 over global sample indices
+ * [sample_begin, sample_begin + sample_count).  With sample_chunks = c > 1 the samples
+ * are summed in c consecutive groups of ceil(count/c) and the group sums are then added
+ * in order (the order in which the GPU combines its per-chunk partial sums). */
+template <class Real, bool FMA> void render(const render_args &A) {
+    scene_t<Real> sc(A.cam, A.spheres, A.n_spheres, A.materials, A.n_materials);
+    const seed_keys keys = keys_from_seed(A.seed);
+    const Real contribution = Real(1) / static_cast<Real>(A.sample_count); /* main.odin:512 */
+    const int64_t chunks = std::max<int64_t>(1, A.sample_chunks);
+    const int64_t per = (A.sample_count + chunks - 1) / chunks;
+    std::atomic<int64_t> next_row{A.region.min_y};
+    std::atomic<uint64_t> total_segments{0};
+    auto work = [&]() {
+        uint64_t segments = 0;
+        for (;;) {
+            int64_t v = next_row.fetch_add(1);
+            if (v >= A.region.one_past_max_y) break;
+            for (int64_t u = A.region.min_x; u < A.region.one_past_max_x; ++u) {
+                vec3<Real> pixel_color{0, 0, 0};
+                for (int64_t c = 0; c < chunks; ++c) {
+                    vec3<Real> part{0, 0, 0};
+                    int64_t lo = c * per, hi = std::min(A.sample_count, (c + 1) * per);
+                    for (int64_t s = lo; s < hi; ++s)
+                        part = part + trace_sample<Real, FMA>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments);
+                    pixel_color = (chunks == 1) ? part : pixel_color + part;
+                }
+                int64_t index = u + v * A.width;
+                if (A.accum) { A.accum[index * 3 + 0] = pixel_color.x; A.accum[index * 3 + 1] = pixel_color.y; A.accum[index * 3 + 2] = pixel_color.z; }
+                pixel_color = pixel_color * contribution; /* main.odin:577 */
+                if (A.linear) { A.linear[index * 3 + 0] = pixel_color.x; A.linear[index * 3 + 1] = pixel_color.y; A.linear[index * 3 + 2] = pixel_color.z; }
+                /* linear to gamma 2  main.odin:581-583 */
+                if (A.image) {
+                    A.image[index * 3 + 0] = std::sqrt(pixel_color.x);
+                    A.image[index * 3 + 1] = std::sqrt(pixel_color.y);
+                    A.image[index * 3 + 2] = std::sqrt(pixel_color.z);
+                }
+            }
+        }
+        total_segments += segments;
+    };
+    int32_t nt = std::max(1, A.threads);
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int32_t i = 0; i < nt; ++i) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    if (A.stats) {
+        uint64_t npix = static_cast<uint64_t>(std::max<int64_t>(0, A.region.one_past_max_x - A.region.min_x)) *
+                        static_cast<uint64_t>(std::max<int64_t>(0, A.region.one_past_max_y - A.region.min_y));
+        A.stats[RT_STAT_SEGMENTS] = total_segments.load();
+        A.stats[RT_STAT_SPHERE_TESTS] = total_segments.load() * static_cast<uint64_t>(A.n_spheres);
+        A.stats[RT_STAT_SAMPLES] = npix * static_cast<uint64_t>(A.sample_count);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t oracle_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t draw) {
+    draw_stream g(keys_from_seed(seed), pixel, sample, bounce);
+    uint32_t u = 0;
+    for (uint32_t i = 0; i <= draw; ++i) u = g.next_u32();
+    return u;
+}
+
+/* precision: RT_PRECISION_F32 (fma scan), RT_PRECISION_F64, RT_PRECISION_F32_LITERAL.
+ * image / linear / accum: optional width*height*3 doubles (gamma image, sample mean, raw sum).
+ * stats: optional RT_STATS_COUNT u64.  threads: worker threads over rows. */
+int32_t oracle_render_region(int32_t precision, double *image, double *linear, double *accum,
+                             int64_t width, int64_t height, rt_rect region,
+                             const rt_camera_render_data *cam,
+                             const rt_sphere *spheres, int64_t n_spheres,
+                             const rt_material *materials, int64_t n_materials,
+                             uint64_t seed, int64_t sample_begin, int64_t sample_count, int64_t sample_chunks,
+                             uint64_t *stats, int32_t threads) {
+    render_args A{width, height, region, cam, spheres, n_spheres, materials, n_materials, seed,
+                  sample_begin, sample_count, sample_chunks, image, linear, accum, stats, threads};
+    switch (precision) {
+    case RT_PRECISION_F64: render<double, false>(A); return 0;
+    case RT_PRECISION_F32: render<float, true>(A); return 0;
+    case RT_PRECISION_F32_LITERAL: render<float, false>(A); return 0;
+    default: return -1;
+    }
+}
+
+/* ray_sphere_intersection with explicit inputs (o, d, c are 3 doubles each) */
+double oracle_ray_sphere_intersection(int32_t precision, const double *o, const double *d, const double *c,
+                                      double radius, double t_min, double t_max) {
+    if (precision == RT_PRECISION_F64) {
+        ray_t<double> r{{o[0], o[1], o[2]}, {d[0], d[1], d[2]}};
+        return ray_sphere_intersection<double, false>(r, {c[0], c[1], c[2]}, radius, t_min, t_max);
+    }
+    ray_t<float> r{{(float)o[0], (float)o[1], (float)o[2]}, {(float)d[0], (float)d[1], (float)d[2]}};
+    vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
+    if (precision == RT_PRECISION_F32) return ray_sphere_intersection<float, true>(r, cf, (float)radius, (float)t_min, (float)t_max);
+    return ray_sphere_intersection<float, false>(r, cf, (float)radius, (float)t_min, (float)t_max);
+}
+
+/* material_scatter for one hit; the draws are those of (seed, pixel, sample, bounce).
+ * out = {origin xyz, direction xyz, attenuation xyz}; returns ok (0/1). */
+int32_t oracle_material_scatter(int32_t precision, const rt_material *m, const double *ray_o, const double *ray_d,
+                                const double *hit_p, const double *hit_normal, int32_t front_face,
+                                uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, double *out) {
+    draw_stream g(keys_from_seed(seed), pixel, sample, bounce);
+    if (precision == RT_PRECISION_F64) {
+        material_t<double> mm{m->type, cvt<double>(m->albedo), m->param1};
+        ray_t<double> r{{ray_o[0], ray_o[1], ray_o[2]}, {ray_d[0], ray_d[1], ray_d[2]}};
+        hit_record<double> h{{hit_p[0], hit_p[1], hit_p[2]}, {hit_normal[0], hit_normal[1], hit_normal[2]}, front_face != 0};
+        auto s = material_scatter(mm, r, h, g);
+        double tmp[9] = {s.ray_out.origin.x, s.ray_out.origin.y, s.ray_out.origin.z, s.ray_out.direction.x, s.ray_out.direction.y,
+                         s.ray_out.direction.z, s.attenuation.x, s.attenuation.y, s.attenuation.z};
+        std::memcpy(out, tmp, sizeof tmp);
+        return s.ok;
+    }
+    material_t<float> mm{m->type, cvt<float>(m->albedo), (float)m->param1};
+    ray_t<float> r{{(float)ray_o[0], (float)ray_o[1], (float)ray_o[2]}, {(float)ray_d[0], (float)ray_d[1], (float)ray_d[2]}};
+    hit_record<float> h{{(float)hit_p[0], (float)hit_p[1], (float)hit_p[2]},
+                        {(float)hit_normal[0], (float)hit_normal[1], (float)hit_normal[2]}, front_face != 0};
+    auto s = material_scatter(mm, r, h, g);
+    double tmp[9] = {s.ray_out.origin.x, s.ray_out.origin.y, s.ray_out.origin.z, s.ray_out.direction.x, s.ray_out.direction.y,
+                     s.ray_out.direction.z, s.attenuation.x, s.attenuation.y, s.attenuation.z};
+    std::memcpy(out, tmp, sizeof tmp);
+    return s.ok;
+}
+
+/* ---- host-side procedures around the path (callers and consumers) ---------------- */
+
+/* lookat  main.odin:65-71.  out = right, up, forward (9 doubles) */
+void oracle_lookat(const double *position, const double *target, const double *axis_up, double *out) {
+    vec3<double> p{position[0], position[1], position[2]}, t{target[0], target[1], target[2]}, a{axis_up[0], axis_up[1], axis_up[2]};
+    vec3<double> forward = normalize(t - p);
+    vec3<double> right = normalize(cross(forward, a));
+    vec3<double> up = cross(right, forward);
+    double tmp[9] = {right.x, right.y, right.z, up.x, up.y, up.z, forward.x, forward.y, forward.z};
+    std::memcpy(out, tmp, sizeof tmp);
+}
+
+/* calculate_camera_render_data  main.odin:450-485 */
+void oracle_calculate_camera_render_data(const rt_camera_settings *cs, rt_camera_render_data *out) {
+    const double TAU = 6.28318530717958647692528676655900576; /* math.TAU */
+    auto turns_to_radians = [&](double t) { return t * TAU; };   /* main.odin:23 */
+    vec3<double> position = cvt<double>(cs->position), right = cvt<double>(cs->right), up = cvt<double>(cs->up), forward = cvt<double>(cs->forward);
+    double half_y = cs->focus_distance * std::tan(turns_to_radians(cs->vfov * 0.5));
+    double half_x = half_y * cs->aspect_ratio;
+    /* view_plane_half_size * 2 / image_size * {1, -1}, element-wise, left to right */
+    double pdx = half_x * 2 / cs->image_size_x * 1.0;
+    double pdy = half_y * 2 / cs->image_size_y * -1.0;
+    vec3<double> du = right * pdx, dv = up * pdy;
+    double tlx = half_x * -1.0 + pdx * 0.5;
+    double tly = half_y * 1.0 + pdy * 0.5;
+    vec3<double> tl = position + forward * cs->focus_distance + right * tlx + up * tly;
+    double dof_radius = cs->focus_distance * std::tan(turns_to_radians(cs->depth_of_field_angle * 0.5));
+    vec3<double> dof_u = right * dof_radius, dof_v = up * dof_radius;
+    auto put = [](rt_v3 &d, vec3<double> s) { d.x = s.x; d.y = s.y; d.z = s.z; };
+    put(out->position, position); put(out->pixel_delta_u, du); put(out->pixel_delta_v, dv);
+    put(out->view_plane_top_left_pixel_center, tl); put(out->dof_disk_u, dof_u); put(out->dof_disk_v, dof_v);
+    out->depth_of_field_angle = cs->depth_of_field_angle;
+    out->samples_per_pixel = cs->samples_per_pixel;
+    out->max_ray_bounces = cs->max_ray_bounces;
+}
+
+/* the quantiser of serialize_ppm  main.odin:812-814: u8(256 * min(x, 0.999)) */
+void oracle_quantize_rgb8(const double *image, int64_t n_values, uint8_t *out) {
+    for (int64_t i = 0; i < n_values; ++i) {
+        double q = 256 * std::min(image[i], 0.999);
+        out[i] = static_cast<uint8_t>(static_cast<int64_t>(q)); /* Odin's u8() cast truncates and wraps */
+    }
+}
+
+/* serialize_ppm  main.odin:791-824.  returns bytes written (dst must hold 32 + 12*w*h). */
+int64_t oracle_serialize_ppm(const double *image, int64_t width, int64_t height, char *dst) {
+    int64_t pos = 0;
+    {   /* fmt.sbprintfln("P3\n%v %v\n255") */
+        char hdr[64];
+        int n = std::snprintf(hdr, sizeof hdr, "P3\n%lld %lld\n255\n", (long long)width, (long long)height);
+        std::memcpy(dst, hdr, n);
+        pos = n;
+    }
+    auto channel = [](char *d, uint8_t u, char sep) { /* serialize_channel  main.odin:797-806 */
+        d[0] = static_cast<char>('0' + ((u / 100) % 10));
+        d[1] = static_cast<char>('0' + ((u / 10) % 10));
+        d[2] = static_cast<char>('0' + (u % 10));
+        d[3] = sep;
+        d[0] = d[0] == '0' ? ' ' : d[0];
+        d[1] = (d[0] == ' ' && d[1] == '0') ? ' ' : d[1];
+    };
+    for (int64_t i = 0; i < width * height; ++i) {
+        uint8_t q[3];
+        oracle_quantize_rgb8(image + i * 3, 3, q);
+        channel(dst + pos + 0, q[0], ' ');
+        channel(dst + pos + 4, q[1], ' ');
+        channel(dst + pos + 8, q[2], '\n');
+        pos += 12;
+    }
+    return pos;
+}
+
+} // extern "C"

@@ -1,0 +1,496 @@
+// C ABI of the library (include/rt_mi355x.h): argument validation, AoS f64 -> SoA upload,
+// launch bookkeeping and the host <-> device copies of the one-shot entry points.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_kernel.h"
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int32_t fail(int32_t code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// One lock per device ordinal: the one-shot entry points may be called from several host
+// threads (the reference calls render_region from pool threads, main.odin:609).
+std::mutex &device_mutex(int device) {
+    static std::mutex m[64];
+    return m[(device >= 0 && device < 64) ? device : 0];
+}
+
+uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+void seed_keys(uint64_t seed, uint32_t &k0, uint32_t &k1) {
+    k0 = mix32(static_cast<uint32_t>(seed) ^ 0x9e3779b9u);
+    k1 = mix32(static_cast<uint32_t>(seed >> 32) ^ k0 ^ 0x85ebca6bu);
+}
+
+bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL; }
+size_t real_size(int32_t precision) { return precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float); }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    hipError_t enter(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (device >= 0 && device != prev) {
+            e = hipSetDevice(device);
+            if (e != hipSuccess) return e;
+            active = true;
+        }
+        return hipSuccess;
+    }
+    ~DeviceGuard() { if (active) (void)hipSetDevice(prev); }
+};
+
+} // namespace
+
+struct rt_world_s {
+    int device = 0;
+    int32_t n_spheres = 0, n_materials = 0;
+    void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
+    void *rad32 = nullptr, *rad64 = nullptr;
+    int32_t *sphere_material = nullptr;
+    void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
+    int32_t *material_type = nullptr;
+    void *slabs = nullptr;                      // partial sums of sample chunks 1..
+    size_t slab_bytes = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+    std::mutex mu;
+};
+
+namespace {
+
+int32_t validate_scene(const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials) {
+    if (n_spheres < 0 || n_materials < 0) return fail(RT_ERR_INVALID_ARGUMENT, "negative element count (%lld spheres, %lld materials)", (long long)n_spheres, (long long)n_materials);
+    if (n_spheres > 0 && spheres == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "spheres is NULL");
+    if (n_materials > 0 && materials == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "materials is NULL");
+    if (n_spheres > (1 << 24) || n_materials > (1 << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 spheres or materials");
+    for (int64_t i = 0; i < n_materials; ++i) {
+        const rt_material &m = materials[i];
+        if (m.type < RT_MATERIAL_LAMBERTIAN || m.type > RT_MATERIAL_DIELECTRIC) return fail(RT_ERR_INVALID_SCENE, "material %lld has unknown type %lld", (long long)i, (long long)m.type);
+        // make_metallic_data asserts 0 <= fuzz <= 1 (main.odin:280)
+        if (m.type == RT_MATERIAL_METALLIC && !(0.0 <= m.param1 && m.param1 <= 1.0)) return fail(RT_ERR_INVALID_SCENE, "metallic material %lld has fuzz %g outside [0, 1]", (long long)i, m.param1);
+        if (m.type == RT_MATERIAL_DIELECTRIC && !(m.param1 > 0.0) ) return fail(RT_ERR_INVALID_SCENE, "dielectric material %lld has refractive index %g <= 0", (long long)i, m.param1);
+    }
+    for (int64_t i = 0; i < n_spheres; ++i) {
+        const rt_sphere &s = spheres[i];
+        if (s.material_index < 0 || s.material_index >= n_materials) return fail(RT_ERR_INVALID_SCENE, "sphere %lld has material_index %lld outside [0, %lld)", (long long)i, (long long)s.material_index, (long long)n_materials);
+        if (!(s.radius != 0.0) || !std::isfinite(s.radius)) return fail(RT_ERR_INVALID_SCENE, "sphere %lld has radius %g", (long long)i, s.radius);
+        if (!std::isfinite(s.center.x) || !std::isfinite(s.center.y) || !std::isfinite(s.center.z)) return fail(RT_ERR_INVALID_SCENE, "sphere %lld has a non-finite centre", (long long)i);
+    }
+    return RT_OK;
+}
+
+struct Work { // validated geometry of one call
+    rtk::TileMap map;
+    int32_t min_x, min_y, max_x, max_y;
+};
+
+int32_t plan_work(int64_t width, int64_t height, rt_rect region, int64_t strip_rows, int32_t strip_index, int32_t strip_count, Work &w) {
+    if (width <= 0 || height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "image size %lld x %lld", (long long)width, (long long)height);
+    if (width * height > (int64_t(1) << 30)) return fail(RT_ERR_UNSUPPORTED, "image of %lld pixels exceeds 2^30", (long long)(width * height));
+    if (region.min_x < 0 || region.min_y < 0 || region.one_past_max_x > width || region.one_past_max_y > height ||
+        region.min_x > region.one_past_max_x || region.min_y > region.one_past_max_y)
+        return fail(RT_ERR_INVALID_ARGUMENT, "region {%lld, %lld, %lld, %lld} is not inside the %lld x %lld image", (long long)region.min_x, (long long)region.min_y,
+                    (long long)region.one_past_max_x, (long long)region.one_past_max_y, (long long)width, (long long)height);
+    if (strip_rows <= 0 || strip_rows % rtk::TILE != 0) return fail(RT_ERR_INVALID_ARGUMENT, "strip_rows %lld is not a positive multiple of 8", (long long)strip_rows);
+    if (strip_count < 1 || strip_index < 0 || strip_index >= strip_count) return fail(RT_ERR_INVALID_ARGUMENT, "strip %d of %d", strip_index, strip_count);
+    const int64_t rw = region.one_past_max_x - region.min_x, rh = region.one_past_max_y - region.min_y;
+    const int64_t tiles_x = (rw + rtk::TILE - 1) / rtk::TILE;
+    const int64_t tile_rows = (rh + rtk::TILE - 1) / rtk::TILE;
+    const int64_t rps = strip_rows / rtk::TILE;
+    const int64_t strips = (tile_rows + rps - 1) / rps;
+    int64_t owned_rows = 0;
+    for (int64_t q = strip_index; q < strips; q += strip_count) owned_rows += std::min<int64_t>(rps, tile_rows - q * rps);
+    w.map.tiles_x = static_cast<int32_t>(tiles_x);
+    w.map.n_tiles = static_cast<int32_t>(tiles_x * owned_rows);
+    w.map.rows_per_strip = static_cast<int32_t>(rps);
+    w.map.strip_index = strip_index;
+    w.map.strip_count = strip_count;
+    w.min_x = static_cast<int32_t>(region.min_x); w.min_y = static_cast<int32_t>(region.min_y);
+    w.max_x = static_cast<int32_t>(region.one_past_max_x); w.max_y = static_cast<int32_t>(region.one_past_max_y);
+    return RT_OK;
+}
+
+void pack_camera(const rt_camera_render_data *cam, rtk::CameraF32 &c32, rtk::CameraF64 &c64) {
+    const rt_v3 *v[6] = {&cam->position, &cam->pixel_delta_u, &cam->pixel_delta_v, &cam->view_plane_top_left_pixel_center, &cam->dof_disk_u, &cam->dof_disk_v};
+    for (int i = 0; i < 6; ++i) {
+        c64.v[3 * i] = v[i]->x; c64.v[3 * i + 1] = v[i]->y; c64.v[3 * i + 2] = v[i]->z;
+    }
+    c64.v[18] = cam->depth_of_field_angle;
+    for (int i = 0; i < 19; ++i) c32.v[i] = static_cast<float>(c64.v[i]);
+}
+
+int auto_chunks(int32_t n_tiles, int64_t sample_count) {
+    // enough waves that the last ones to finish are short next to the whole launch
+    const int64_t target_waves = 32768;
+    int64_t c = (target_waves + n_tiles - 1) / std::max(1, n_tiles);
+    c = std::min<int64_t>(c, std::max<int64_t>(1, sample_count / 16));
+    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(c, 32)));
+}
+
+std::atomic<uint64_t> g_call_counter{0};
+
+} // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+const char *rt_last_error(void) { return g_error.c_str(); }
+
+int32_t rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+void rt_options_default(rt_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->rng_mode = RT_RNG_DETERMINISTIC;
+    o->precision = RT_PRECISION_F32;
+    o->sphere_fetch = RT_FETCH_AUTO;
+    o->device = -1;
+    o->device_count = 1;
+}
+
+int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials, int32_t device, rt_world **out) {
+    if (out == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int32_t rc = validate_scene(spheres, n_spheres, materials, n_materials);
+    if (rc != RT_OK) return rc;
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(device));
+    int current = 0;
+    HIP_TRY(hipGetDevice(&current));
+
+    const size_t ns = static_cast<size_t>(n_spheres), nm = static_cast<size_t>(n_materials);
+    std::vector<float> rec32(4 * ns), rad32(ns), mat32(4 * nm);
+    std::vector<double> rec64(4 * ns), rad64(ns), mat64(4 * nm);
+    std::vector<int32_t> smat(ns), mtype(nm);
+    for (size_t i = 0; i < ns; ++i) {
+        const rt_sphere &s = spheres[i];
+        const float r = static_cast<float>(s.radius);
+        rec32[4 * i + 0] = static_cast<float>(s.center.x); rec32[4 * i + 1] = static_cast<float>(s.center.y);
+        rec32[4 * i + 2] = static_cast<float>(s.center.z); rec32[4 * i + 3] = r * r; // sphere_radius*sphere_radius, main.odin:248
+        rec64[4 * i + 0] = s.center.x; rec64[4 * i + 1] = s.center.y; rec64[4 * i + 2] = s.center.z; rec64[4 * i + 3] = s.radius * s.radius;
+        rad32[i] = r; rad64[i] = s.radius;
+        smat[i] = static_cast<int32_t>(s.material_index);
+    }
+    for (size_t i = 0; i < nm; ++i) {
+        const rt_material &m = materials[i];
+        mat64[4 * i + 0] = m.albedo.x; mat64[4 * i + 1] = m.albedo.y; mat64[4 * i + 2] = m.albedo.z; mat64[4 * i + 3] = m.param1;
+        for (int k = 0; k < 4; ++k) mat32[4 * i + k] = static_cast<float>(mat64[4 * i + k]);
+        mtype[i] = static_cast<int32_t>(m.type);
+    }
+    rt_world *w = new rt_world_s();
+    w->device = current;
+    w->n_spheres = static_cast<int32_t>(n_spheres);
+    w->n_materials = static_cast<int32_t>(n_materials);
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 64));
+        if (e != hipSuccess) return e;
+        if (bytes == 0) return hipSuccess;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = upload(&w->rec32, rec32.data(), rec32.size() * 4);
+    if (e == hipSuccess) e = upload(&w->rec64, rec64.data(), rec64.size() * 8);
+    if (e == hipSuccess) e = upload(&w->rad32, rad32.data(), rad32.size() * 4);
+    if (e == hipSuccess) e = upload(&w->rad64, rad64.data(), rad64.size() * 8);
+    if (e == hipSuccess) e = upload(reinterpret_cast<void **>(&w->sphere_material), smat.data(), smat.size() * 4);
+    if (e == hipSuccess) e = upload(&w->mat32, mat32.data(), mat32.size() * 4);
+    if (e == hipSuccess) e = upload(&w->mat64, mat64.data(), mat64.size() * 8);
+    if (e == hipSuccess) e = upload(reinterpret_cast<void **>(&w->material_type), mtype.data(), mtype.size() * 4);
+    if (e == hipSuccess) e = hipEventCreate(&w->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&w->ev_end);
+    if (e != hipSuccess) {
+        rt_world_destroy(w);
+        return fail(RT_ERR_DEVICE, "uploading the world failed: %s", hipGetErrorString(e));
+    }
+    *out = w;
+    return RT_OK;
+}
+
+int32_t rt_world_destroy(rt_world *w) {
+    if (w == nullptr) return RT_OK;
+    DeviceGuard guard;
+    (void)guard.enter(w->device);
+    void *bufs[] = {w->rec32, w->rec64, w->rad32, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
+    if (w->ev_end) (void)hipEventDestroy(w->ev_end);
+    delete w;
+    return RT_OK;
+}
+
+int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
+                             int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                             int64_t sample_begin, int64_t sample_count, uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                             int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
+    if (world == nullptr || cam == nullptr || d_accum == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, cam or d_accum is NULL");
+    if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
+    if (sphere_fetch != RT_FETCH_AUTO && sphere_fetch != RT_FETCH_SCALAR && sphere_fetch != RT_FETCH_LDS) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
+    if (sample_begin < 0 || sample_count < 0 || sample_begin + sample_count > (int64_t(1) << 32) - 2) return fail(RT_ERR_INVALID_ARGUMENT, "samples [%lld, +%lld) outside [0, 2^32-2)", (long long)sample_begin, (long long)sample_count);
+    if (cam->max_ray_bounces < 0 || cam->max_ray_bounces > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "max_ray_bounces %lld outside [0, 2^20]", (long long)cam->max_ray_bounces);
+    if (sample_chunks < 0) return fail(RT_ERR_INVALID_ARGUMENT, "sample_chunks %d < 0", sample_chunks);
+    Work wk;
+    int32_t rc = plan_work(width, height, region, strip_rows, strip_index, strip_count, wk);
+    if (rc != RT_OK) return rc;
+    if (wk.map.n_tiles == 0) return RT_OK;
+
+    const bool f64 = precision == RT_PRECISION_F64;
+    int fetch = sphere_fetch == RT_FETCH_AUTO ? RT_FETCH_SCALAR : sphere_fetch;
+    if (fetch == RT_FETCH_LDS && world->n_spheres > (f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32))
+        return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_LDS holds at most %d spheres at this precision, the world has %d",
+                    f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32, world->n_spheres);
+
+    int chunks = sample_chunks > 0 ? sample_chunks : auto_chunks(wk.map.n_tiles, sample_count);
+    chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, sample_count))));
+    const int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
+    chunks = sample_count == 0 ? 1 : static_cast<int>((sample_count + chunk_samples - 1) / chunk_samples);
+
+    std::lock_guard<std::mutex> lock(world->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(world->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t slab_stride = width * height * 3;
+    if (chunks > 1) {
+        const size_t need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * real_size(precision);
+        if (need > world->slab_bytes) {
+            if (world->slabs) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(world->slabs)); world->slabs = nullptr; world->slab_bytes = 0; }
+            HIP_TRY(hipMalloc(&world->slabs, need));
+            world->slab_bytes = need;
+        }
+    }
+
+    rtk::RenderParams p{};
+    p.sphere_rec = f64 ? world->rec64 : world->rec32;
+    p.sphere_radius = f64 ? world->rad64 : world->rad32;
+    p.sphere_material = world->sphere_material;
+    p.material_rec = f64 ? world->mat64 : world->mat32;
+    p.material_type = world->material_type;
+    p.n_spheres = world->n_spheres;
+    p.width = static_cast<int32_t>(width); p.height = static_cast<int32_t>(height);
+    p.min_x = wk.min_x; p.min_y = wk.min_y; p.max_x = wk.max_x; p.max_y = wk.max_y;
+    p.map = wk.map;
+    p.sample_begin = static_cast<uint32_t>(sample_begin);
+    p.sample_count = static_cast<uint32_t>(sample_count);
+    p.chunk_samples = static_cast<uint32_t>(chunk_samples);
+    p.max_bounces = static_cast<int32_t>(cam->max_ray_bounces);
+    seed_keys(seed, p.k0, p.k1);
+    p.accum = d_accum;
+    p.slabs = world->slabs;
+    p.slab_stride = slab_stride;
+    p.stats = reinterpret_cast<unsigned long long *>(d_stats);
+    pack_camera(cam, p.cam32, p.cam64);
+
+    HIP_TRY(hipEventRecord(world->ev_begin, st));
+    HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, st));
+    if (chunks > 1) {
+        rtk::ReduceParams r{};
+        r.accum = d_accum; r.slabs = world->slabs; r.slab_stride = slab_stride; r.chunks = chunks;
+        r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
+        HIP_TRY(rtk::launch_reduce(r, precision, st));
+    }
+    HIP_TRY(hipEventRecord(world->ev_end, st));
+    world->timed = true;
+    return RT_OK;
+}
+
+int64_t rt_world_last_kernel_ns(rt_world *world) {
+    if (world == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world is NULL");
+    std::lock_guard<std::mutex> lock(world->mu);
+    if (!world->timed) return fail(RT_ERR_INVALID_ARGUMENT, "no render has been launched on this world");
+    DeviceGuard guard;
+    if (guard.enter(world->device) != hipSuccess) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    hipError_t e = hipEventSynchronize(world->ev_end);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, world->ev_begin, world->ev_end);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventElapsedTime failed: %s", hipGetErrorString(e));
+    return static_cast<int64_t>(static_cast<double>(ms) * 1e6);
+}
+
+int32_t rt_finalize(rt_world *world, const void *d_accum, int32_t precision, int64_t width, int64_t height, rt_rect region,
+                    int64_t strip_rows, int32_t strip_index, int32_t strip_count, int64_t total_samples,
+                    rt_v3 *d_image, rt_v3 *d_linear, void *stream) {
+    if (world == nullptr || d_accum == nullptr || d_image == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, d_accum or d_image is NULL");
+    if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
+    if (total_samples <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "total_samples %lld <= 0", (long long)total_samples);
+    Work wk;
+    int32_t rc = plan_work(width, height, region, strip_rows, strip_index, strip_count, wk);
+    if (rc != RT_OK) return rc;
+    if (wk.map.n_tiles == 0) return RT_OK;
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(world->device));
+    rtk::FinalizeParams f{};
+    f.accum = d_accum;
+    f.image = reinterpret_cast<double *>(d_image);
+    f.linear = reinterpret_cast<double *>(d_linear);
+    f.total_samples = total_samples;
+    f.width = static_cast<int32_t>(width);
+    f.min_x = wk.min_x; f.min_y = wk.min_y; f.max_x = wk.max_x; f.max_y = wk.max_y; f.map = wk.map;
+    HIP_TRY(rtk::launch_finalize(f, precision, static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_rect region, const rt_camera_render_data *cam,
+                         const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                         const rt_options *opts) {
+    rt_options o;
+    if (opts) o = *opts; else rt_options_default(&o);
+    if (image_data == nullptr || cam == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "image_data or cam is NULL");
+    if (!precision_ok(o.precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", o.precision);
+    if (o.rng_mode != RT_RNG_STOCHASTIC && o.rng_mode != RT_RNG_DETERMINISTIC) return fail(RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %d", o.rng_mode);
+    // the reference divides by samples_per_pixel (main.odin:512); zero or negative counts have no meaningful image
+    if (cam->samples_per_pixel < 1) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel %lld < 1", (long long)cam->samples_per_pixel);
+    int32_t rc = validate_scene(spheres, n_spheres, materials, n_materials);
+    if (rc != RT_OK) return rc;
+    Work probe;
+    rc = plan_work(width, height, region, rtk::TILE, 0, 1, probe);
+    if (rc != RT_OK) return rc;
+    if (o.stats) std::memset(o.stats, 0, sizeof(uint64_t) * RT_STATS_COUNT);
+    if (probe.map.n_tiles == 0) return RT_OK; // empty region: nothing to render, nothing written
+
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    int first = o.device;
+    if (first < 0) HIP_TRY(hipGetDevice(&first));
+    const int count = std::max(1, o.device_count);
+    if (first >= n_dev || first + count > n_dev) return fail(RT_ERR_DEVICE, "devices [%d, %d) requested, %d visible", first, first + count, n_dev);
+
+    uint64_t seed = o.seed;
+    if (o.rng_mode == RT_RNG_STOCHASTIC) {
+        const uint64_t tick = static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count());
+        seed ^= (tick * 0x9e3779b97f4a7c15ull) ^ ((g_call_counter.fetch_add(1) + 1) * 0xbf58476d1ce4e5b9ull);
+    }
+
+    struct PerDevice {
+        int device = 0; rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr;
+        uint64_t *stats = nullptr; hipStream_t stream = nullptr;
+    };
+    std::vector<PerDevice> devs(count);
+    const size_t n_px = static_cast<size_t>(width) * static_cast<size_t>(height);
+    const int64_t strip_rows = rtk::TILE; // 8-row strips dealt round-robin over the devices
+    int32_t result = RT_OK;
+    auto cleanup = [&]() {
+        for (auto &d : devs) {
+            (void)hipSetDevice(d.device);
+            if (d.stream) { (void)hipStreamSynchronize(d.stream); (void)hipStreamDestroy(d.stream); }
+            if (d.accum) (void)hipFree(d.accum);
+            if (d.image) (void)hipFree(d.image);
+            if (d.linear) (void)hipFree(d.linear);
+            if (d.stats) (void)hipFree(d.stats);
+            rt_world_destroy(d.world);
+        }
+    };
+    int prev_device = 0;
+    HIP_TRY(hipGetDevice(&prev_device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int g = 0; g < count; ++g) locks.emplace_back(device_mutex(first + g));
+
+    // launch everything on every device, then collect
+    for (int g = 0; g < count && result == RT_OK; ++g) {
+        PerDevice &d = devs[g];
+        d.device = first + g;
+        hipError_t e = hipSetDevice(d.device);
+        if (e == hipSuccess) e = hipStreamCreate(&d.stream);
+        if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * real_size(o.precision));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.image), n_px * 3 * sizeof(double));
+        if (e == hipSuccess && o.linear_out) e = hipMalloc(reinterpret_cast<void **>(&d.linear), n_px * 3 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.stats), sizeof(uint64_t) * RT_STATS_COUNT);
+        if (e == hipSuccess) e = hipMemsetAsync(d.stats, 0, sizeof(uint64_t) * RT_STATS_COUNT, d.stream);
+        if (e != hipSuccess) { result = fail(RT_ERR_DEVICE, "device %d set-up failed: %s", d.device, hipGetErrorString(e)); break; }
+        result = rt_world_create(spheres, n_spheres, materials, n_materials, d.device, &d.world);
+        if (result != RT_OK) break;
+        result = rt_render_accumulate(d.world, cam, width, height, region, strip_rows, g, count, 0, cam->samples_per_pixel, seed, o.precision,
+                                      o.sphere_fetch, o.sample_chunks, d.accum, d.stats, d.stream);
+        if (result != RT_OK) break;
+        result = rt_finalize(d.world, d.accum, o.precision, width, height, region, strip_rows, g, count, cam->samples_per_pixel,
+                             reinterpret_cast<rt_v3 *>(d.image), reinterpret_cast<rt_v3 *>(d.linear), d.stream);
+    }
+    // copy each device's strips of the region back: rows [y0, y1), columns of the region
+    const size_t pitch = static_cast<size_t>(width) * sizeof(rt_v3);
+    const size_t row_bytes = static_cast<size_t>(region.one_past_max_x - region.min_x) * sizeof(rt_v3);
+    for (int g = 0; g < count && result == RT_OK; ++g) {
+        PerDevice &d = devs[g];
+        hipError_t e = hipSetDevice(d.device);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+        for (int64_t y0 = region.min_y + g * strip_rows; e == hipSuccess && y0 < region.one_past_max_y; y0 += strip_rows * count) {
+            const int64_t y1 = std::min<int64_t>(region.one_past_max_y, count == 1 ? region.one_past_max_y : y0 + strip_rows);
+            const size_t off = static_cast<size_t>(y0) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x);
+            e = hipMemcpy2D(image_data + off, pitch, reinterpret_cast<rt_v3 *>(d.image) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && o.linear_out)
+                e = hipMemcpy2D(o.linear_out + off, pitch, reinterpret_cast<rt_v3 *>(d.linear) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
+            if (count == 1) break;
+        }
+        if (e == hipSuccess && o.stats) {
+            uint64_t h[RT_STATS_COUNT];
+            e = hipMemcpy(h, d.stats, sizeof h, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                o.stats[RT_STAT_SEGMENTS] += h[RT_STAT_SEGMENTS];
+                o.stats[RT_STAT_SAMPLES] += h[RT_STAT_SAMPLES];
+                const int64_t ns = rt_world_last_kernel_ns(d.world);
+                if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
+            }
+        }
+        if (e != hipSuccess) result = fail(RT_ERR_DEVICE, "collecting from device %d failed: %s", d.device, hipGetErrorString(e));
+    }
+    if (result == RT_OK && o.stats) o.stats[RT_STAT_SPHERE_TESTS] = o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
+    const std::string keep = g_error;
+    cleanup();
+    (void)hipSetDevice(prev_device);
+    if (result != RT_OK) g_error = keep;
+    return result;
+}
+
+int32_t rt_render_tiled(rt_v3 *image_data, int64_t width, int64_t height, const rt_camera_render_data *cam,
+                        const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                        const rt_options *opts) {
+    rt_rect whole = {0, 0, width, height};
+    return rt_render_region(image_data, width, height, whole, cam, spheres, n_spheres, materials, n_materials, opts);
+}
+
+uint32_t rt_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t draw) {
+    uint32_t k0, k1;
+    seed_keys(seed, k0, k1);
+    const uint32_t kp = mix32(k0 ^ pixel), wp = mix32(k1 + pixel);
+    const uint32_t ks = mix32(kp + 0x9e3779b9u * (sample + 1u));
+    const uint32_t kb = mix32(ks ^ (0x85ebca6bu * (bounce + 1u)));
+    return mix32(kb + 0xc2b2ae35u * (draw + 1u)) ^ wp;
+}
+
+} // extern "C"

@@ -1,0 +1,75 @@
+// Interface between the C-ABI shim (rt_api.cpp) and the gfx950 kernels (rt_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+constexpr int TILE = 8;              // a wave64 owns one 8x8-pixel tile, lane l -> (l & 7, l >> 3)
+constexpr int WAVES_PER_BLOCK = 4;   // 256-thread workgroups: four tiles share one LDS copy of the spheres
+constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+constexpr int REJECTION_CAP = 64;    // bound on the two rejection-sampling loops (P(reaching it) < 1e-20)
+constexpr int LDS_MAX_SPHERES_F32 = 4096; // 64 KiB of float4 records per workgroup
+constexpr int LDS_MAX_SPHERES_F64 = 2048; // 64 KiB of double4 records per workgroup
+
+enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2 };
+enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2 };
+
+// camera_render_data (main.odin:440-448) as 19 numbers in the kernel's arithmetic type:
+// position, pixel_delta_u, pixel_delta_v, view_plane_top_left_pixel_center, dof_disk_u,
+// dof_disk_v (3 each) and depth_of_field_angle.
+struct CameraF32 { float v[19]; };
+struct CameraF64 { double v[19]; };
+
+// Which 8-row tile rows of the region a launch owns: tile row k of the launch is tile row
+// ((k / rows_per_strip) * strip_count + strip_index) * rows_per_strip + k % rows_per_strip
+// of the region.
+struct TileMap {
+    int32_t tiles_x;        // tiles per tile row
+    int32_t n_tiles;        // tiles owned by this launch
+    int32_t rows_per_strip; // tile rows per strip
+    int32_t strip_index, strip_count;
+};
+
+struct RenderParams {
+    // world, structure of arrays (device pointers)
+    const void *sphere_rec;     // per sphere {cx, cy, cz, r*r} in float4 / double4
+    const void *sphere_radius;  // per sphere radius, float / double
+    const int32_t *sphere_material;
+    const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
+    const int32_t *material_type;
+    int32_t n_spheres;
+    // image and work
+    int32_t width, height;
+    int32_t min_x, min_y, max_x, max_y; // region, half open
+    TileMap map;
+    uint32_t sample_begin;   // first global sample index of the call
+    uint32_t sample_count;   // samples of the call
+    uint32_t chunk_samples;  // samples per chunk (blockIdx.y = chunk)
+    int32_t max_bounces;
+    uint32_t k0, k1;         // RNG seed keys
+    void *accum;             // chunk 0 writes here: width*height*3 sums in float / double
+    void *slabs;             // chunk c >= 1 writes to slabs + (c-1)*slab_stride (same layout)
+    int64_t slab_stride;     // elements per slab
+    unsigned long long *stats; // optional device counters
+    CameraF32 cam32;
+    CameraF64 cam64;
+};
+
+hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, hipStream_t stream);
+
+struct ReduceParams {
+    void *accum; const void *slabs; int64_t slab_stride; int32_t chunks;
+    int32_t width; int32_t min_x, min_y, max_x, max_y; TileMap map;
+};
+// accum[p] = accum[p] + slab_0[p] + slab_1[p] + ... (chunk order) for the pixels the TileMap owns
+hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream);
+
+struct FinalizeParams {
+    const void *accum; double *image; double *linear; // image/linear: 3 doubles per pixel
+    int64_t total_samples;
+    int32_t width; int32_t min_x, min_y, max_x, max_y; TileMap map;
+};
+hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream);
+
+} // namespace rtk

@@ -1,0 +1,419 @@
+// gfx950 kernels of the path tracer: the loops of render_region (main.odin:510-591).
+//
+// Work decomposition
+//   wave64  = one 8x8-pixel tile, lane = pixel.  blockIdx.y = sample chunk.
+//   Every lane runs ONE flat loop whose iteration is one ray segment: the closest-hit scan
+//   over all spheres, then shading.  A lane whose path ended starts its next sample in the
+//   same iteration, so lanes never wait for the longest path of a sample; a wave ends when
+//   its slowest pixel has traced all samples of the chunk.
+// Closest-hit scan
+//   The sphere index is wave-uniform.  Per sphere a lane spends 3 subtractions, 3+3 fused
+//   multiply-adds for h = d.oc and |oc|^2 - r^2, and a multiply + fma for the discriminant
+//   (main.odin:245-249 with a = |d|^2 and r^2 hoisted).  Only when some lane's line
+//   meets the sphere does the wave leave the straight-line code; such a lane parks the
+//   candidate (h, disc, index) in registers and the square root / divisions / range tests of
+//   main.odin:252-261 run later, for all parked lanes at once, when a lane needs its slot
+//   again or the scan ends.  A lane's candidates are still resolved in sphere order with
+//   the shrinking t_max of main.odin:541-545, so results equal the straight loop's.
+// Arithmetic
+//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma() calls
+//   of the F32_FMA scan.  Division and square root are IEEE correctly rounded.  Everything
+//   outside the scan follows the reference's operation order.
+#include "rt_kernel.h"
+
+namespace rtk {
+
+// ----------------------------------------------------------------------------- small math
+template <typename Real> struct V3 { Real x, y, z; };
+template <typename Real> __device__ __forceinline__ V3<Real> operator+(V3<Real> a, V3<Real> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator-(V3<Real> a, V3<Real> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator-(V3<Real> a) { return {-a.x, -a.y, -a.z}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator*(V3<Real> a, V3<Real> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator*(Real s, V3<Real> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator*(V3<Real> a, Real s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename Real> __device__ __forceinline__ V3<Real> operator/(V3<Real> a, Real s) { return {a.x / s, a.y / s, a.z / s}; }
+// dot (main.odin:28-30): left to right, no fusion
+template <typename Real> __device__ __forceinline__ Real dot(V3<Real> a, V3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float abs_rn(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double abs_rn(double x) { return __builtin_fabs(x); }
+template <typename Real> __device__ __forceinline__ Real min_std(Real a, Real b) { return (b < a) ? b : a; } // std::min
+template <typename Real> __device__ __forceinline__ Real max_std(Real a, Real b) { return (a < b) ? b : a; } // std::max
+template <typename Real> __device__ __forceinline__ V3<Real> normalize(V3<Real> v) { return v / sqrt_rn(dot(v, v)); } // main.odin:48-50
+
+template <typename Real> struct Lim;
+template <> struct Lim<float> { static constexpr float max_v = 3.402823466e+38f; static constexpr float eps = 1.1920928955078125e-07f; };
+template <> struct Lim<double> { static constexpr double max_v = 1.7976931348623157e+308; static constexpr double eps = 2.220446049250313e-16; };
+
+template <typename Real> struct Rec4;
+template <> struct Rec4<float> { using type = float4; };
+template <> struct Rec4<double> { using type = double4; };
+
+// ----------------------------------------------------------------------------- counter RNG
+// draw j (1-based) of stream (pixel, sample, bounce): mix32(kb + 0xc2b2ae35*j) ^ wp with
+//   kp = mix32(k0 ^ pixel), wp = mix32(k1 + pixel), ks = mix32(kp + 0x9e3779b9*(sample+1)),
+//   kb = mix32(ks ^ 0x85ebca6b*(bounce+1)).   bounce 0 = camera draws, k+1 = scatter at segment k.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+struct Draws {
+    uint32_t kb, wp, c;
+    __device__ __forceinline__ Draws(uint32_t ks, uint32_t wp_, uint32_t bounce) : kb(mix32(ks ^ (0x85ebca6bu * (bounce + 1u)))), wp(wp_), c(0) {}
+    __device__ __forceinline__ uint32_t next_u32() { c += 0xc2b2ae35u; return mix32(kb + c) ^ wp; }
+    // rand.float64(): uniform [0,1) with 24 random bits, exact in f32 and f64
+    template <typename Real> __device__ __forceinline__ Real next() { return static_cast<Real>(next_u32() >> 8) * static_cast<Real>(1.0 / 16777216.0); }
+    // rand.float64_range(lo, hi): (hi-lo)*u + lo, a result that reaches hi is pulled back below it
+    template <typename Real> __device__ __forceinline__ Real range(Real lo, Real hi) {
+        Real val = (hi - lo) * next<Real>() + lo;
+        if (val >= hi) val = max_std(lo, hi * (Real(1) - Lim<Real>::eps));
+        return val;
+    }
+};
+
+// random_unit_vector (main.odin:194-203)
+template <typename Real> __device__ __forceinline__ V3<Real> random_unit_vector(Draws &g) {
+    const Real hi = Real(1) + Real(2.220446049250313e-16); // 1 + F64_EPSILON, rounds to 1 in f32
+    V3<Real> p = {Real(0), Real(0), Real(0)};
+    Real lsq = Real(0);
+    for (int it = 0; it < REJECTION_CAP; ++it) {
+        p.x = g.range<Real>(Real(-1), hi);
+        p.y = g.range<Real>(Real(-1), hi);
+        p.z = g.range<Real>(Real(-1), hi);
+        lsq = dot(p, p);
+        if (Real(0) < lsq && lsq <= Real(1)) break;
+    }
+    return p / sqrt_rn(lsq);
+}
+
+// ----------------------------------------------------------------------------- optics
+// reflect (main.odin:77-80)
+template <typename Real> __device__ __forceinline__ V3<Real> reflect(V3<Real> v, V3<Real> n) { return v - (Real(2) * dot(v, n)) * n; }
+// refract_with_relative_refractive_index, arithmetic (main.odin:168-173)
+template <typename Real> __device__ __forceinline__ V3<Real> refract(V3<Real> v, V3<Real> n, Real rel) {
+    Real cos_theta = min_std(dot(-v, n), Real(1));
+    V3<Real> perp = rel * (v + cos_theta * n);
+    V3<Real> par = (-sqrt_rn(max_std(Real(1) - dot(perp, perp), Real(0)))) * n;
+    return perp + par;
+}
+
+// ----------------------------------------------------------------------------- the kernel
+template <typename Real> __device__ __forceinline__ const Real *camera_of(const RenderParams &p);
+template <> __device__ __forceinline__ const float *camera_of<float>(const RenderParams &p) { return p.cam32.v; }
+template <> __device__ __forceinline__ const double *camera_of<double>(const RenderParams &p) { return p.cam64.v; }
+
+template <typename Real> __device__ __forceinline__ V3<Real> cam3(const Real *c, int i) { return {c[3 * i], c[3 * i + 1], c[3 * i + 2]}; }
+
+__device__ __forceinline__ int tile_row_of(const TileMap &m, int k) {
+    return ((k / m.rows_per_strip) * m.strip_count + m.strip_index) * m.rows_per_strip + (k % m.rows_per_strip);
+}
+
+template <typename Real, bool FMA, int FETCH>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParams P) {
+    using R4 = typename Rec4<Real>::type;
+    const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
+    const int n = P.n_spheres;
+
+    extern __shared__ double4 lds_raw[];
+    const R4 *rec = g_rec;
+    if (FETCH == FETCH_LDS) {
+        R4 *l_rec = reinterpret_cast<R4 *>(lds_raw);
+        for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
+        __syncthreads();
+        rec = l_rec;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (tile >= P.map.n_tiles) return; // whole wave
+    const int tx = tile % P.map.tiles_x;
+    const int ty = tile_row_of(P.map, tile / P.map.tiles_x);
+    const int u = P.min_x + tx * TILE + (lane & 7);
+    const int v = P.min_y + ty * TILE + (lane >> 3);
+    const bool inside = (u < P.max_x) && (v < P.max_y);
+
+    const uint32_t chunk = blockIdx.y;
+    uint32_t s = chunk * P.chunk_samples;                            // sample index within the call
+    const uint32_t s_end = min(P.sample_count, s + P.chunk_samples);
+    bool alive = inside && (s < s_end);
+
+    const Real *C = camera_of<Real>(P);
+    const uint32_t pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
+    const uint32_t kp = mix32(P.k0 ^ pixel);
+    const uint32_t wp = mix32(P.k1 + pixel);
+
+    V3<Real> ro = {Real(0), Real(0), Real(0)}, rd = {Real(0), Real(0), Real(0)}; // ray
+    V3<Real> color = {Real(1), Real(1), Real(1)};                                // sample_color
+    V3<Real> acc = {Real(0), Real(0), Real(0)};                                  // pixel_color
+    uint32_t ks = 0;
+    int bounce = 0;
+    bool fresh = true;
+    uint32_t segments = 0;
+
+    while (alive) {
+        if (fresh) {
+            // camera ray of global sample sample_begin + s (main.odin:519-534)
+            ks = mix32(kp + 0x9e3779b9u * (P.sample_begin + s + 1u));
+            Draws g(ks, wp, 0u);
+            Real jx = g.range<Real>(Real(-0.5), Real(0.5));
+            Real jy = g.range<Real>(Real(-0.5), Real(0.5));
+            V3<Real> psp = cam3(C, 3) + (static_cast<Real>(u) + jx) * cam3(C, 1) + (static_cast<Real>(v) + jy) * cam3(C, 2);
+            ro = cam3(C, 0);
+            if (C[18] > Real(0)) {
+                // random_point_on_disk (main.odin:214-223)
+                const Real hi = Real(1) + Real(2.220446049250313e-16);
+                Real px = Real(0), py = Real(0);
+                for (int it = 0; it < REJECTION_CAP; ++it) {
+                    px = g.range<Real>(Real(-1), hi);
+                    py = g.range<Real>(Real(-1), hi);
+                    if (px * px + py * py <= Real(1)) break;
+                }
+                ro = ro + ((px * cam3(C, 4)) + (py * cam3(C, 5)));
+            }
+            rd = psp - ro;
+            color = {Real(1), Real(1), Real(1)};
+            bounce = 0;
+            fresh = false;
+        }
+
+        // ---------------- closest-hit scan (main.odin:536-546 with :240-263 inlined)
+        const Real a = dot(rd, rd);
+        const Real t_min = static_cast<Real>(0.001); // SHADOW_ACNE_RAY_OFFSET
+        Real closest = Lim<Real>::max_v;
+        int hit = -1;
+        Real pend_h = Real(0), pend_disc = Real(0);
+        int pend = -1;
+
+        auto resolve = [&]() {
+            // main.odin:252-261 for the parked candidate, then :542-545
+            Real sq = sqrt_rn(pend_disc);
+            Real root = (pend_h - sq) / a;
+            bool rejected = (root < t_min) || (closest <= root);
+            if (rejected) {
+                root = (pend_h + sq) / a;
+                rejected = (root < t_min) || (closest <= root);
+            }
+            if (!rejected && root < closest) { closest = root; hit = pend; }
+            pend = -1;
+        };
+
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            const R4 sp = rec[i];
+            const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
+            Real h, cc, disc;
+            if (FMA) {
+                h = fma_rn(rd.z, ocz, fma_rn(rd.y, ocy, rd.x * ocx));
+                cc = fma_rn(ocz, ocz, fma_rn(ocy, ocy, fma_rn(ocx, ocx, -sp.w)));
+                disc = fma_rn(h, h, -(a * cc));
+            } else {
+                h = rd.x * ocx + rd.y * ocy + rd.z * ocz;
+                cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                disc = h * h - a * cc;
+            }
+            if (__builtin_amdgcn_ballot_w64(disc >= Real(0)) != 0ull) {
+                // A line that meets the sphere only behind the origin (h <= 0) while the origin
+                // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
+                const bool cand = (disc >= Real(0)) && ((h > Real(0)) || (cc < Real(0)));
+                if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
+                    if (pend >= 0) resolve();
+                }
+                if (cand) { pend_h = h; pend_disc = disc; pend = i; }
+            }
+        }
+        if (pend >= 0) resolve();
+        ++segments;
+
+        // ---------------- shading
+        bool ended;
+        if (hit >= 0) {
+            const R4 sp = g_rec[hit];
+            const Real radius = static_cast<const Real *>(P.sphere_radius)[hit];
+            const int mi = P.sphere_material[hit];
+            const int mtype = P.material_type[mi];
+            const R4 m = static_cast<const R4 *>(P.material_rec)[mi];
+            // hit record (main.odin:553-557)
+            const V3<Real> center = {sp.x, sp.y, sp.z};
+            const V3<Real> p = ro + closest * rd;
+            V3<Real> nrm = (p - center) / radius;
+            const bool front = dot(rd, nrm) < Real(0);
+            nrm = front ? nrm : -nrm;
+            Draws g(ks, wp, static_cast<uint32_t>(bounce) + 1u);
+            V3<Real> dir;
+            V3<Real> atten = {m.x, m.y, m.z};
+            bool ok = true;
+            if (mtype == 2) {
+                // dielectric_proc (main.odin:356-400)
+                const Real ri = m.w;
+                Real src = (ri >= Real(1)) ? Real(1) : Real(1) / ri;
+                Real dst = (ri >= Real(1)) ? ri : Real(1);
+                if (!front) { Real t = src; src = dst; dst = t; }
+                const Real rel = src / dst;
+                const V3<Real> unit = normalize(rd);
+                Real cos_theta = dot(-unit, nrm);
+                cos_theta = min_std(cos_theta, Real(1));
+                const Real sin2 = Real(1) - cos_theta * cos_theta;
+                const bool must_reflect = (rel * rel * sin2) > Real(1);
+                bool do_reflect = must_reflect;
+                if (!must_reflect) {
+                    // Schlick (main.odin:111-122); the uniform is drawn only on this branch (:390)
+                    Real r0 = (Real(1) - rel) / (Real(1) + rel);
+                    r0 *= r0;
+                    const Real q = Real(1) - cos_theta;
+                    const Real refl = r0 + (Real(1) - r0) * q * q * q * q * q;
+                    do_reflect = refl > g.next<Real>();
+                }
+                dir = do_reflect ? reflect(unit, nrm) : refract(unit, nrm, rel);
+                atten = {Real(1), Real(1), Real(1)};
+            } else {
+                const V3<Real> ruv = random_unit_vector<Real>(g);
+                if (mtype == 0) {
+                    // lambertian_proc (main.odin:292-312)
+                    dir = nrm + ruv;
+                    const Real EPS = static_cast<Real>(1e-8);
+                    if (abs_rn(dir.x) <= EPS && abs_rn(dir.y) <= EPS && abs_rn(dir.z) <= EPS) dir = nrm;
+                } else {
+                    // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
+                    dir = normalize(reflect(rd, nrm));
+                    dir = dir + m.w * ruv;
+                    ok = dot(dir, nrm) > Real(0);
+                }
+            }
+            if (ok) {
+                ro = p; rd = dir;
+                color = color * atten;
+                ++bounce;
+                ended = bounce > P.max_bounces; // `for _ in 0..=max_ray_bounces` ran out: colour is kept (main.odin:535)
+            } else {
+                color = {Real(0), Real(0), Real(0)};
+                ended = true;
+            }
+        } else {
+            // background (main.odin:570-572, :412-418): lerp(a, b, t) = a*(1-t) + b*t
+            const V3<Real> d = normalize(rd);
+            const Real t = Real(0.5) * (d.y + Real(1));
+            const V3<Real> wa = {Real(1), Real(1), Real(1)};
+            const V3<Real> wb = {static_cast<Real>(0.5), static_cast<Real>(0.7), static_cast<Real>(1.0)};
+            color = color * (wa * (Real(1) - t) + wb * t);
+            ended = true;
+        }
+        if (ended) {
+            acc = acc + color; // main.odin:575
+            ++s;
+            fresh = true;
+            alive = s < s_end;
+        }
+    }
+
+    if (inside) {
+        Real *out = (chunk == 0 ? static_cast<Real *>(P.accum) : static_cast<Real *>(P.slabs) + static_cast<int64_t>(chunk - 1) * P.slab_stride) +
+                    static_cast<int64_t>(pixel) * 3;
+        out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+    }
+    if (P.stats != nullptr) {
+        // wave totals: segments traced and camera rays started
+        uint32_t seg = segments;
+        uint32_t smp = inside ? (s_end > chunk * P.chunk_samples ? s_end - chunk * P.chunk_samples : 0u) : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            seg += __shfl_xor(seg, off, 64);
+            smp += __shfl_xor(smp, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&P.stats[0], static_cast<unsigned long long>(seg));
+            atomicAdd(&P.stats[3], static_cast<unsigned long long>(smp));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- small kernels
+// thread -> owned pixel: the same tile enumeration as render_kernel, 64 pixels per tile
+__device__ __forceinline__ bool owned_pixel(const TileMap &m, int min_x, int min_y, int max_x, int max_y, int width, int64_t &index) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int tile = static_cast<int>(gid >> 6);
+    const int lane = static_cast<int>(gid & 63);
+    if (tile >= m.n_tiles) return false;
+    const int u = min_x + (tile % m.tiles_x) * TILE + (lane & 7);
+    const int v = min_y + tile_row_of(m, tile / m.tiles_x) * TILE + (lane >> 3);
+    if (u >= max_x || v >= max_y) return false;
+    index = static_cast<int64_t>(u) + static_cast<int64_t>(v) * width;
+    return true;
+}
+
+template <typename Real> __global__ void reduce_kernel(const ReduceParams P) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    Real *base = static_cast<Real *>(P.accum) + idx * 3;
+    Real x = base[0], y = base[1], z = base[2];
+    for (int c = 1; c < P.chunks; ++c) {
+        const Real *sl = static_cast<const Real *>(P.slabs) + static_cast<int64_t>(c - 1) * P.slab_stride + idx * 3;
+        x = x + sl[0]; y = y + sl[1]; z = z + sl[2];
+    }
+    base[0] = x; base[1] = y; base[2] = z;
+}
+
+// main.odin:577-586: pixel_color *= 1/spp, per-channel sqrt, store
+template <typename Real> __global__ void finalize_kernel(const FinalizeParams P) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    const Real *in = static_cast<const Real *>(P.accum) + idx * 3;
+    const Real contribution = Real(1) / static_cast<Real>(P.total_samples);
+    const Real mx = in[0] * contribution, my = in[1] * contribution, mz = in[2] * contribution;
+    if (P.linear != nullptr) {
+        P.linear[idx * 3 + 0] = static_cast<double>(mx);
+        P.linear[idx * 3 + 1] = static_cast<double>(my);
+        P.linear[idx * 3 + 2] = static_cast<double>(mz);
+    }
+    P.image[idx * 3 + 0] = static_cast<double>(sqrt_rn(mx));
+    P.image[idx * 3 + 1] = static_cast<double>(sqrt_rn(my));
+    P.image[idx * 3 + 2] = static_cast<double>(sqrt_rn(mz));
+}
+
+// ----------------------------------------------------------------------------- launchers
+template <typename Real, bool FMA>
+static hipError_t launch_render_t(const RenderParams &p, int fetch, int chunks, hipStream_t stream) {
+    const int blocks = (p.map.n_tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks <= 0 || chunks <= 0) return hipSuccess;
+    dim3 grid(blocks, chunks, 1), block(BLOCK_THREADS, 1, 1);
+    if (fetch == FETCH_LDS) {
+        size_t lds = static_cast<size_t>(p.n_spheres) * sizeof(typename Rec4<Real>::type);
+        hipLaunchKernelGGL((render_kernel<Real, FMA, FETCH_LDS>), grid, block, lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((render_kernel<Real, FMA, FETCH_SCALAR>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, hipStream_t stream) {
+    switch (arith) {
+    case ARITH_F32_FMA: return launch_render_t<float, true>(p, fetch, chunks, stream);
+    case ARITH_F64: return launch_render_t<double, false>(p, fetch, chunks, stream);
+    case ARITH_F32_LITERAL: return launch_render_t<float, false>(p, fetch, chunks, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
+    const int64_t threads = static_cast<int64_t>(p.map.n_tiles) * 64;
+    if (threads <= 0 || p.chunks <= 1) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
+    if (arith == ARITH_F64) hipLaunchKernelGGL(reduce_kernel<double>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(reduce_kernel<float>, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream) {
+    const int64_t threads = static_cast<int64_t>(p.map.n_tiles) * 64;
+    if (threads <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
+    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_kernel<double>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(finalize_kernel<float>, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace rtk

@@ -1,0 +1,100 @@
+// Measures the FP32 vector rate of the chip with dependent-free v_fma_f32 and v_pk_fma_f32
+// streams at several occupancies, and the in-kernel clock, so that the roofline's peak can
+// be quoted next to a number measured on the same box.
+//   usage: valu_peak            (prints one line per variant, then a JSON summary line)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int ACC = 16;   // independent accumulators per lane
+constexpr int ITERS = 4096;
+
+__global__ void fma_scalar(float *out, float b, float c) {
+    float acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = threadIdx.x * 1e-6f + i;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(b), "v"(c));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    if (s == 123.456f) out[0] = s; // never true: keeps the chain alive
+}
+
+__global__ void fma_packed(float *out, float b, float c) {
+    v2f acc[ACC / 2];
+    const v2f vb = {b, b * 1.0001f}, vc = {c, c * 0.9999f};
+#pragma unroll
+    for (int i = 0; i < ACC / 2; ++i) acc[i] = v2f{threadIdx.x * 1e-6f + i, threadIdx.x * 2e-6f + i};
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC / 2; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(vb), "v"(vc));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC / 2; ++i) s += acc[i].x + acc[i].y;
+    if (s == 123.456f) out[0] = s;
+}
+
+// 3 sub + 6 fma + 2 mul-class: the instruction mix of the ray/sphere test, no memory, no branch
+__global__ void sphere_mix(float *out, float b, float c) {
+    float ox = threadIdx.x * 1e-3f, oy = 0.5f, oz = -0.25f, dx = 0.3f, dy = b, dz = c, a = dx * dx + dy * dy + dz * dz;
+    float best = 0.f;
+    for (int it = 0; it < ITERS; ++it) {
+        float cx = it * 1e-3f, cy = b * it, cz = c - it;
+        float x = cx - ox, y = cy - oy, z = cz - oz;
+        float h = __builtin_fmaf(dz, z, __builtin_fmaf(dy, y, dx * x));
+        float cc = __builtin_fmaf(z, z, __builtin_fmaf(y, y, __builtin_fmaf(x, x, -0.04f)));
+        float disc = __builtin_fmaf(h, h, -(a * cc));
+        best = disc > best ? disc : best;
+    }
+    if (best == 123.456f) out[0] = best;
+}
+
+template <class K> double run(K kernel, int blocks_per_cu, int threads, float *d) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int grid = 256 * blocks_per_cu;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, 0, d, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, 0, d, 1.0001f, 0.5f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / 10 < best) best = ms / 10;
+    }
+    return best * 1e-3; // seconds per launch
+}
+
+int main() {
+    float *d; CHECK(hipMalloc(&d, 4096));
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s  CUs %d  clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+    double best_scalar = 0, best_packed = 0, best_mix = 0;
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        // 256-thread blocks = 1 wave per SIMD per block; blocks_per_cu = waves per SIMD
+        const double flops = 256.0 * waves_per_simd * 256 * double(ITERS) * ACC * 2;
+        double ts = run(fma_scalar, waves_per_simd, 256, d);
+        double tp = run(fma_packed, waves_per_simd, 256, d);
+        const double mix_flops = 256.0 * waves_per_simd * 256 * double(ITERS) * 17;
+        double tm = run(sphere_mix, waves_per_simd, 256, d);
+        printf("waves/SIMD %d: v_fma_f32 %.1f TFLOP/s   v_pk_fma_f32 %.1f TFLOP/s   sphere-mix %.1f TFLOP/s (17 FLOP/test)\n", waves_per_simd,
+               flops / ts * 1e-12, flops / tp * 1e-12, mix_flops / tm * 1e-12);
+        if (flops / ts > best_scalar) best_scalar = flops / ts;
+        if (flops / tp > best_packed) best_packed = flops / tp;
+        if (mix_flops / tm > best_mix) best_mix = mix_flops / tm;
+    }
+    printf("{\"v_fma_f32_tflops\": %.2f, \"v_pk_fma_f32_tflops\": %.2f, \"sphere_mix_tflops\": %.2f, \"spec_tflops\": 157.3}\n",
+           best_scalar * 1e-12, best_packed * 1e-12, best_mix * 1e-12);
+    return 0;
+}
