@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one full render of the workload: every pixel, every sample, through the C ABI
+(rt_render_accumulate + rt_finalize), with the world and camera already resident in HBM.
+Workload at N=1: the book's final random-spheres scene, 1200x675, 500 spp, depth 50.
+N>1 (one process per GPU, launched by torch.distributed.run): sample split -- rank r traces
+global sample indices [r*500, (r+1)*500) of every pixel, the Q32.32 accumulators are summed with
+an RCCL all-reduce over xGMI and rank 0 finalises a 500*N-spp image (weak scaling: per-GPU
+work is fixed).  `--partition rows` instead deals 8-row strips of ONE 500-spp frame over the
+ranks and gathers them on rank 0 (strong scaling).
+
+Prints one JSON line on rank 0 with the driver's fields plus `roofline` (FP32 VALU) and
+`cpu_baseline` (the f64 CPU restatement of the reference timed on this host's cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_TEST = 17                 # algorithmic FLOP per ray/sphere test (3 sub, 5+5 dot products, -r^2, h*h-a*c)
+PEAK_FP32_TFLOPS = 157.3    # MI355X vector FP32 peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--scene", default="final", choices=["final", "dev", "stress"])
+    ap.add_argument("--partition", default="samples", choices=["samples", "rows"])
+    ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds"])
+    ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
+    """The oracle (CPU restatement of the reference, f64, its literal operation order) on a
+    bounded sample of the same workload: the full frame at the spp that fits the time budget."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.Oracle()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    probe = (0, height // 2, width, height // 2 + 8)  # 8 rows through the middle of the frame
+    t0 = time.perf_counter()
+    o.render_region(width, height, probe, cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    est_full_1spp = dt * height / 8.0
+    spp = max(1, min(64, int(seconds / max(est_full_1spp, 1e-3))))
+    t0 = time.perf_counter()
+    r = o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=spp, threads=cores)
+    dt = time.perf_counter() - t0
+    samples = width * height * spp
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"full {width}x{height} frame at {spp} spp ({samples} samples, {dt:.1f} s), f64, {cores} threads over rows",
+            "segments_per_sample": float(r["stats"][0]) / samples}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rt = importlib.import_module("raytracing-in-one-weekend_amd")
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 as: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.scene == "final":
+        cs, sph, mat = rt.build_final_scene(1, args.width)
+    elif args.scene == "dev":
+        cs, sph, mat = rt.build_dev_scene(args.width)
+    else:
+        cs, sph, mat = rt.build_stress_scene(5, 10000, args.width)
+    cs.samples_per_pixel = args.spp
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS}[args.fetch]
+
+    world = rt.World(sph, mat, device=local_rank)
+    accum = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums: exact, so the all-reduce is order-independent
+    image = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+    gathered = torch.zeros_like(image)
+    stats = torch.zeros(rt.STATS_COUNT, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    by_samples = args.partition == "samples"
+    total_spp = args.spp * world_size if by_samples else args.spp
+
+    def step(collect_stats=False):
+        if by_samples:
+            world.render_accumulate(cam, w, h, accum.data_ptr(), sample_begin=rank * args.spp, sample_count=args.spp, seed=1,
+                                    sphere_fetch=fetch, sample_chunks=args.chunks, d_stats=stats.data_ptr() if collect_stats else 0, stream=stream)
+            if world_size > 1:
+                dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                world.finalize(accum.data_ptr(), w, h, total_spp, image.data_ptr(), stream=stream)
+        else:
+            world.render_accumulate(cam, w, h, accum.data_ptr(), strip_rows=8, strip_index=rank, strip_count=world_size, sample_count=args.spp,
+                                    seed=1, sphere_fetch=fetch, sample_chunks=args.chunks, d_stats=stats.data_ptr() if collect_stats else 0, stream=stream)
+            world.finalize(accum.data_ptr(), w, h, total_spp, image.data_ptr(), strip_rows=8, strip_index=rank, strip_count=world_size, stream=stream)
+            if world_size > 1:
+                # rank 0 gathers the strips: every rank's image is zero outside its own strips
+                gathered.copy_(image)
+                dist.reduce(gathered, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one counted pass: exact segment count of this rank's share of a step
+    step(collect_stats=True)
+    torch.cuda.synchronize()
+    segments = int(stats[rt.STAT_SEGMENTS].item())
+    samples_rank = int(stats[rt.STAT_SAMPLES].item())
+    wave_iters = int(stats[rt.STAT_WAVE_ITERATIONS].item())
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    knl = []
+    for _ in range(args.steps):
+        step()
+        # device time of this step's render kernel: HIP events recorded around it on the launch stream
+        knl.append(world.last_kernel_ns())
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_s = sum(knl) / len(knl) * 1e-9
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    seg_t = torch.tensor([segments, samples_rank], dtype=torch.int64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    samples_step = w * h * total_spp
+    value = samples_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        tests_rank = segments * len(sph)
+        achieved = F_TEST * tests_rank / kernel_s / 1e12
+        out = {
+            "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak",
+            "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if by_samples else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} scene ({len(sph)} spheres, seed 1) {w}x{h}, {args.spp} spp per GPU, depth {cs.max_ray_bounces}",
+                       "partition": ("sample split + RCCL all-reduce" if by_samples else "8-row strips + RCCL reduce to rank 0") if world_size > 1 else "single GPU",
+                       "total_spp": total_spp, "sphere_fetch": args.fetch, "rng": "counter, deterministic, seed 1"},
+            "pct_fp32_peak": 100.0 * achieved / PEAK_FP32_TFLOPS,
+            "segments_per_sample": segments / max(1, samples_rank),
+            "lane_utilization": segments / max(1, 64 * wave_iters),
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": None, "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
+                         "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(rt, cam, sph, mat, w, h, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    world.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,7 +61,7 @@ typedef struct {
     int64_t max_ray_bounces;
 } rt_camera_render_data;
 
-/* camera_settings                                           main.odin:425-438 (176 B)
+/* camera_settings                                           main.odin:425-438 (160 B)
  * image_size is v2 ([2]f64); vfov and depth_of_field_angle are in turns. */
 typedef struct {
     rt_v3 position, right, up, forward;
@@ -80,7 +80,8 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 /* ---- options ------------------------------------------------------------ */
 
 /* arithmetic the kernel computes in */
-#define RT_PRECISION_F32 0         /* f32, fused multiply-adds in the ray/sphere test (throughput path)      */
+#define RT_PRECISION_F32 0         /* f32 paths, fused multiply-adds in the ray/sphere test, exact Q32.32 sample
+                                      sums, f64 mean and square root (throughput path)                       */
 #define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
 #define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
 
@@ -97,6 +98,8 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 #define RT_STAT_SPHERE_TESTS 1 /* segments * n_spheres = calls of ray_sphere_intersection main.odin:541   */
 #define RT_STAT_KERNEL_NS 2    /* device time of the render kernels of this call, from HIP events          */
 #define RT_STAT_SAMPLES 3      /* camera rays started                                                       */
+#define RT_STAT_WAVE_ITERATIONS 4 /* sum over wave64s of their segment-loop trip count: segments / (64 * this)
+                                  is the share of lanes that had a live ray in the closest-hit scan         */
 #define RT_STATS_COUNT 8
 
 typedef struct {
@@ -175,9 +178,14 @@ int32_t rt_world_destroy(rt_world *world);
  *            strip_rows satisfies s % strip_count == strip_index
  *            (strip_count 1 = the whole region; strip_rows a multiple of 8);
  *   samples: the global sample indices [sample_begin, sample_begin+sample_count).
- * d_accum is a device buffer of width*height*3 elements (float for the F32
- * precisions, double for F64) indexed [(u + v*width)*3 + channel]; the call
- * overwrites the entries of its pixels with the SUM of its samples' colours.
+ * d_accum is a device buffer of width*height*3 elements indexed
+ * [(u + v*width)*3 + channel]; the call overwrites the entries of its pixels
+ * with the SUM of its samples' colours.  Element type by precision:
+ *   RT_PRECISION_F32         uint64_t, Q32.32 fixed point (each f32 sample colour is
+ *                            truncated to 2^-32 and added exactly, so sums over any
+ *                            split of the samples -- chunks, calls, GPUs -- are equal);
+ *   RT_PRECISION_F64         double, summed in sample order as main.odin:575;
+ *   RT_PRECISION_F32_LITERAL float, summed in sample order.
  * cam->samples_per_pixel is ignored here.  d_stats is NULL or a device array
  * of RT_STATS_COUNT u64 the kernel adds RT_STAT_SEGMENTS / RT_STAT_SAMPLES
  * into.  `stream` is a hipStream_t (NULL = the default stream); the call is
@@ -195,9 +203,10 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam,
 
 /*
  * The tail of the pixel loop (main.odin:577-586) on the device: for the
- * pixels selected as above, mean = accum / total_samples, and
+ * pixels selected as above, mean = accum * (1 / total_samples), and
  * d_image[u + v*width] = sqrt(mean) per channel (device rt_v3 array);
- * d_linear, if not NULL, receives the mean itself.
+ * d_linear, if not NULL, receives the mean itself.  d_accum has the element
+ * type rt_render_accumulate documents for `precision`.
  */
 int32_t rt_finalize(rt_world *world, const void *d_accum, int32_t precision,
                     int64_t width, int64_t height, rt_rect region,

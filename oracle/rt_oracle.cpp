@@ -20,8 +20,9 @@
  *                              main.odin:19; LLVM does not contract a*b+c without fast-math).
  * Real = float,  FMA = false : the same operation order in f32.
  * Real = float,  FMA = true  : as above, but the three dot-product chains of the
- *                              ray/sphere test use fused multiply-adds -- the arithmetic
- *                              of the GPU throughput kernel.
+ *                              ray/sphere test use fused multiply-adds, and sample colours
+ *                              are summed exactly in Q32.32 with an f64 mean and square
+ *                              root -- the arithmetic of the GPU throughput kernel.
  */
 #include <algorithm>
 #include <atomic>
@@ -352,14 +353,34 @@ struct render_args {
     int32_t threads;
 };
 
+/* Q32.32 fixed point of a non-negative f32, truncated below 2^-32 (NaN and negatives -> 0):
+ * the accumulator format of the GPU throughput kernel, whose lanes finish samples in no
+ * fixed order and therefore need a sum that does not depend on the order of addition. */
+inline uint64_t to_q32_32(float x) {
+    if (!(x > 0.0f)) return 0;
+    if (x >= 4294967296.0f) return 0xFFFFFFFF00000000ull;
+    const uint32_t hi = static_cast<uint32_t>(x);
+    const float fr = x - static_cast<float>(hi);
+    const uint32_t lo = static_cast<uint32_t>(fr * 4294967296.0f);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+inline double q32_32_to_f64(uint64_t v) {
+    return static_cast<double>(static_cast<uint32_t>(v >> 32)) * 4294967296.0 + static_cast<double>(static_cast<uint32_t>(v));
+}
+
 /* render_region  main.odin:510-591 over global sample indices
- * [sample_begin, sample_begin + sample_count).  With sample_chunks = c > 1 the samples
- * are summed in c consecutive groups of ceil(count/c) and the group sums are then added
- * in order (the order in which the GPU combines its per-chunk partial sums). */
-template <class Real, bool FMA> void render(const render_args &A) {
+ * [sample_begin, sample_begin + sample_count).
+ * QACC = false: pixel_color is a Real sum in sample order, the mean and the gamma square root
+ *   are taken in Real (the reference's loop).  With sample_chunks = c > 1 the samples are summed
+ *   in c consecutive groups of ceil(count/c) and the group sums are then added in order (the
+ *   order in which the GPU combines its per-chunk partial sums).
+ * QACC = true (f32 throughput arithmetic): each f32 sample colour is converted to Q32.32 and
+ *   summed exactly in u64; mean and square root are taken in f64. */
+template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
     scene_t<Real> sc(A.cam, A.spheres, A.n_spheres, A.materials, A.n_materials);
     const seed_keys keys = keys_from_seed(A.seed);
     const Real contribution = Real(1) / static_cast<Real>(A.sample_count); /* main.odin:512 */
+    const double contribution64 = 1.0 / static_cast<double>(A.sample_count);
     const int64_t chunks = std::max<int64_t>(1, A.sample_chunks);
     const int64_t per = (A.sample_count + chunks - 1) / chunks;
     std::atomic<int64_t> next_row{A.region.min_y};
@@ -370,6 +391,21 @@ template <class Real, bool FMA> void render(const render_args &A) {
             int64_t v = next_row.fetch_add(1);
             if (v >= A.region.one_past_max_y) break;
             for (int64_t u = A.region.min_x; u < A.region.one_past_max_x; ++u) {
+                const int64_t index = u + v * A.width;
+                if (QACC) {
+                    uint64_t q[3] = {0, 0, 0};
+                    for (int64_t s = 0; s < A.sample_count; ++s) {
+                        vec3<Real> c = trace_sample<Real, FMA>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments);
+                        q[0] += to_q32_32(static_cast<float>(c.x)); q[1] += to_q32_32(static_cast<float>(c.y)); q[2] += to_q32_32(static_cast<float>(c.z));
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double mean = (q32_32_to_f64(q[k]) * (1.0 / 4294967296.0)) * contribution64;
+                        if (A.accum) A.accum[index * 3 + k] = static_cast<double>(q[k]); /* exact below 2^53 */
+                        if (A.linear) A.linear[index * 3 + k] = mean;
+                        if (A.image) A.image[index * 3 + k] = std::sqrt(mean);
+                    }
+                    continue;
+                }
                 vec3<Real> pixel_color{0, 0, 0};
                 for (int64_t c = 0; c < chunks; ++c) {
                     vec3<Real> part{0, 0, 0};
@@ -378,7 +414,6 @@ template <class Real, bool FMA> void render(const render_args &A) {
                         part = part + trace_sample<Real, FMA>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments);
                     pixel_color = (chunks == 1) ? part : pixel_color + part;
                 }
-                int64_t index = u + v * A.width;
                 if (A.accum) { A.accum[index * 3 + 0] = pixel_color.x; A.accum[index * 3 + 1] = pixel_color.y; A.accum[index * 3 + 2] = pixel_color.z; }
                 pixel_color = pixel_color * contribution; /* main.odin:577 */
                 if (A.linear) { A.linear[index * 3 + 0] = pixel_color.x; A.linear[index * 3 + 1] = pixel_color.y; A.linear[index * 3 + 2] = pixel_color.z; }
@@ -432,9 +467,9 @@ int32_t oracle_render_region(int32_t precision, double *image, double *linear, d
     render_args A{width, height, region, cam, spheres, n_spheres, materials, n_materials, seed,
                   sample_begin, sample_count, sample_chunks, image, linear, accum, stats, threads};
     switch (precision) {
-    case RT_PRECISION_F64: render<double, false>(A); return 0;
-    case RT_PRECISION_F32: render<float, true>(A); return 0;
-    case RT_PRECISION_F32_LITERAL: render<float, false>(A); return 0;
+    case RT_PRECISION_F64: render<double, false, false>(A); return 0;
+    case RT_PRECISION_F32: render<float, true, true>(A); return 0;
+    case RT_PRECISION_F32_LITERAL: render<float, false, false>(A); return 0;
     default: return -1;
     }
 }

@@ -29,7 +29,7 @@ LAMBERTIAN, METALLIC, DIELECTRIC = 0, 1, 2
 PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL = 0, 1, 2
 FETCH_AUTO, FETCH_SCALAR, FETCH_LDS = 0, 1, 2
 RNG_STOCHASTIC, RNG_DETERMINISTIC = 0, 1
-STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES = 0, 1, 2, 3
+STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES, STAT_WAVE_ITERATIONS = 0, 1, 2, 3, 4
 STATS_COUNT = 8
 
 # numpy views of the 40-byte Odin structs (main.odin:487-491, :285-289)
@@ -104,6 +104,14 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no fallback implementation")
+    # PyTorch-ROCm wheels carry their own libamdhip64.so.7.  A process must run ONE HIP runtime:
+    # with torch imported first, this library's DT_NEEDED libamdhip64.so.7 binds to the copy
+    # torch already mapped (same SONAME); loaded the other way round, torch would map a second
+    # runtime next to the system one and find no devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
     P = C.POINTER

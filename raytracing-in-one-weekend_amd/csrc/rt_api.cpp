@@ -54,7 +54,7 @@ void seed_keys(uint64_t seed, uint32_t &k0, uint32_t &k1) {
 }
 
 bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL; }
-size_t real_size(int32_t precision) { return precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float); }
+size_t accum_size(int32_t precision) { return rtk::accum_element_size(precision); }
 
 struct DeviceGuard {
     int prev = -1;
@@ -76,7 +76,9 @@ struct DeviceGuard {
 
 struct rt_world_s {
     int device = 0;
-    int32_t n_spheres = 0, n_materials = 0;
+    int32_t n_spheres = 0, n_padded = 0, n_materials = 0;
+    int resident_blocks = 2048;                 // workgroups the device can hold at once
+    uint32_t *queue = nullptr;                  // head of the work queue of the throughput kernel
     void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
     void *rad32 = nullptr, *rad64 = nullptr;
     int32_t *sphere_material = nullptr;
@@ -160,6 +162,12 @@ int auto_chunks(int32_t n_tiles, int64_t sample_count) {
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(c, 32)));
 }
 
+int auto_queue_chunks(int64_t sample_count) {
+    // work items of about 16 samples per pixel: small enough that the items still running when
+    // the queue empties are a sliver of the launch, large enough that taking one is free
+    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + 15) / 16, 4096)));
+}
+
 std::atomic<uint64_t> g_call_counter{0};
 
 } // namespace
@@ -197,8 +205,13 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     HIP_TRY(hipGetDevice(&current));
 
     const size_t ns = static_cast<size_t>(n_spheres), nm = static_cast<size_t>(n_materials);
-    std::vector<float> rec32(4 * ns), rad32(ns), mat32(4 * nm);
-    std::vector<double> rec64(4 * ns), rad64(ns), mat64(4 * nm);
+    // records are padded to a multiple of GROUP, plus one group the scan may prefetch; a pad
+    // record has r*r = -inf, which makes its discriminant -inf (or NaN): never a candidate
+    const size_t ns_pad = (ns + rtk::GROUP - 1) / rtk::GROUP * rtk::GROUP;
+    const size_t ns_alloc = ns_pad + rtk::GROUP;
+    std::vector<float> rec32(4 * ns_alloc, 0.0f), rad32(ns), mat32(4 * nm);
+    std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
+    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; }
     std::vector<int32_t> smat(ns), mtype(nm);
     for (size_t i = 0; i < ns; ++i) {
         const rt_sphere &s = spheres[i];
@@ -218,6 +231,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     rt_world *w = new rt_world_s();
     w->device = current;
     w->n_spheres = static_cast<int32_t>(n_spheres);
+    w->n_padded = static_cast<int32_t>(ns_pad);
     w->n_materials = static_cast<int32_t>(n_materials);
     auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 64));
@@ -234,6 +248,14 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     if (e == hipSuccess) e = upload(&w->mat32, mat32.data(), mat32.size() * 4);
     if (e == hipSuccess) e = upload(&w->mat64, mat64.data(), mat64.size() * 8);
     if (e == hipSuccess) e = upload(reinterpret_cast<void **>(&w->material_type), mtype.data(), mtype.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w->queue), 64);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, current);
+        // 2048 threads per CU = 8 workgroups of 256; a grid larger than what is resident is harmless
+        // (late workgroups find the queue empty), a smaller one would leave CUs idle
+        if (e == hipSuccess) w->resident_blocks = std::max(1, prop.multiProcessorCount) * (2048 / rtk::BLOCK_THREADS);
+    }
     if (e == hipSuccess) e = hipEventCreate(&w->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&w->ev_end);
     if (e != hipSuccess) {
@@ -248,7 +270,7 @@ int32_t rt_world_destroy(rt_world *w) {
     if (w == nullptr) return RT_OK;
     DeviceGuard guard;
     (void)guard.enter(w->device);
-    void *bufs[] = {w->rec32, w->rec64, w->rad32, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs};
+    void *bufs[] = {w->rec32, w->rec64, w->rad32, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
@@ -277,18 +299,20 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_LDS holds at most %d spheres at this precision, the world has %d",
                     f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32, world->n_spheres);
 
-    int chunks = sample_chunks > 0 ? sample_chunks : auto_chunks(wk.map.n_tiles, sample_count);
+    const bool queue_mode = precision == RT_PRECISION_F32;
+    int chunks = sample_chunks > 0 ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count) : auto_chunks(wk.map.n_tiles, sample_count));
     chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, sample_count))));
     const int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
     chunks = sample_count == 0 ? 1 : static_cast<int>((sample_count + chunk_samples - 1) / chunk_samples);
+    if (static_cast<int64_t>(wk.map.n_tiles) * chunks > (int64_t(1) << 31) - 1) return fail(RT_ERR_UNSUPPORTED, "%d tiles x %d sample chunks exceed 2^31 work items", wk.map.n_tiles, chunks);
 
     std::lock_guard<std::mutex> lock(world->mu);
     DeviceGuard guard;
     HIP_TRY(guard.enter(world->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t slab_stride = width * height * 3;
-    if (chunks > 1) {
-        const size_t need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * real_size(precision);
+    if (chunks > 1 && !queue_mode) {
+        const size_t need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * accum_size(precision);
         if (need > world->slab_bytes) {
             if (world->slabs) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(world->slabs)); world->slabs = nullptr; world->slab_bytes = 0; }
             HIP_TRY(hipMalloc(&world->slabs, need));
@@ -302,13 +326,15 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     p.sphere_material = world->sphere_material;
     p.material_rec = f64 ? world->mat64 : world->mat32;
     p.material_type = world->material_type;
-    p.n_spheres = world->n_spheres;
+    p.n_spheres = world->n_padded;
     p.width = static_cast<int32_t>(width); p.height = static_cast<int32_t>(height);
     p.min_x = wk.min_x; p.min_y = wk.min_y; p.max_x = wk.max_x; p.max_y = wk.max_y;
     p.map = wk.map;
     p.sample_begin = static_cast<uint32_t>(sample_begin);
     p.sample_count = static_cast<uint32_t>(sample_count);
     p.chunk_samples = static_cast<uint32_t>(chunk_samples);
+    p.n_items = static_cast<uint32_t>(static_cast<int64_t>(wk.map.n_tiles) * chunks);
+    p.queue = world->queue;
     p.max_bounces = static_cast<int32_t>(cam->max_ray_bounces);
     seed_keys(seed, p.k0, p.k1);
     p.accum = d_accum;
@@ -317,14 +343,13 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     p.stats = reinterpret_cast<unsigned long long *>(d_stats);
     pack_camera(cam, p.cam32, p.cam64);
 
+    rtk::ReduceParams r{};
+    r.accum = d_accum; r.slabs = world->slabs; r.slab_stride = slab_stride; r.chunks = chunks;
+    r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
     HIP_TRY(hipEventRecord(world->ev_begin, st));
-    HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, st));
-    if (chunks > 1) {
-        rtk::ReduceParams r{};
-        r.accum = d_accum; r.slabs = world->slabs; r.slab_stride = slab_stride; r.chunks = chunks;
-        r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
-        HIP_TRY(rtk::launch_reduce(r, precision, st));
-    }
+    if (queue_mode) HIP_TRY(rtk::launch_clear(r, world->queue, st));
+    HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, world->resident_blocks, st));
+    if (chunks > 1 && !queue_mode) HIP_TRY(rtk::launch_reduce(r, precision, st));
     HIP_TRY(hipEventRecord(world->ev_end, st));
     world->timed = true;
     return RT_OK;
@@ -428,7 +453,7 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
         d.device = first + g;
         hipError_t e = hipSetDevice(d.device);
         if (e == hipSuccess) e = hipStreamCreate(&d.stream);
-        if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * real_size(o.precision));
+        if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * accum_size(o.precision));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.image), n_px * 3 * sizeof(double));
         if (e == hipSuccess && o.linear_out) e = hipMalloc(reinterpret_cast<void **>(&d.linear), n_px * 3 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.stats), sizeof(uint64_t) * RT_STATS_COUNT);
@@ -463,6 +488,7 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
             if (e == hipSuccess) {
                 o.stats[RT_STAT_SEGMENTS] += h[RT_STAT_SEGMENTS];
                 o.stats[RT_STAT_SAMPLES] += h[RT_STAT_SAMPLES];
+                o.stats[RT_STAT_WAVE_ITERATIONS] += h[RT_STAT_WAVE_ITERATIONS];
                 const int64_t ns = rt_world_last_kernel_ns(d.world);
                 if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
             }

@@ -8,11 +8,16 @@ namespace rtk {
 constexpr int TILE = 8;              // a wave64 owns one 8x8-pixel tile, lane l -> (l & 7, l >> 3)
 constexpr int WAVES_PER_BLOCK = 4;   // 256-thread workgroups: four tiles share one LDS copy of the spheres
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+constexpr int GROUP = 4;             // sphere records are fetched and tested four at a time
 constexpr int REJECTION_CAP = 64;    // bound on the two rejection-sampling loops (P(reaching it) < 1e-20)
-constexpr int LDS_MAX_SPHERES_F32 = 4096; // 64 KiB of float4 records per workgroup
-constexpr int LDS_MAX_SPHERES_F64 = 2048; // 64 KiB of double4 records per workgroup
+constexpr int LDS_MAX_SPHERES_F32 = 4088; // just under 64 KiB of float4 records per workgroup
+constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 records per workgroup
 
+// ARITH_F32_FMA    : f32, fused scan, work queue, accumulators are Q32.32 in uint64 (atomic adds)
+// ARITH_F64        : f64, reference operation order, accumulators are double
+// ARITH_F32_LITERAL: f32, reference operation order, accumulators are float
 enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2 };
+inline size_t accum_element_size(int arith) { return arith == ARITH_F32_LITERAL ? 4 : 8; }
 enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2 };
 
 // camera_render_data (main.odin:440-448) as 19 numbers in the kernel's arithmetic type:
@@ -38,17 +43,19 @@ struct RenderParams {
     const int32_t *sphere_material;
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
     const int32_t *material_type;
-    int32_t n_spheres;
+    int32_t n_spheres;          // padded to a multiple of GROUP (pad records have r*r = -inf); GROUP more follow
     // image and work
     int32_t width, height;
     int32_t min_x, min_y, max_x, max_y; // region, half open
     TileMap map;
     uint32_t sample_begin;   // first global sample index of the call
     uint32_t sample_count;   // samples of the call
-    uint32_t chunk_samples;  // samples per chunk (blockIdx.y = chunk)
+    uint32_t chunk_samples;  // samples per chunk
+    uint32_t n_items;        // queue mode: n_tiles * chunks work items, item = chunk * n_tiles + tile
+    uint32_t *queue;         // queue mode: head of the work queue (zeroed before the launch)
     int32_t max_bounces;
     uint32_t k0, k1;         // RNG seed keys
-    void *accum;             // chunk 0 writes here: width*height*3 sums in float / double
+    void *accum;             // width*height*3 sums (element type: see Arith); literal modes: chunk 0 writes here
     void *slabs;             // chunk c >= 1 writes to slabs + (c-1)*slab_stride (same layout)
     int64_t slab_stride;     // elements per slab
     unsigned long long *stats; // optional device counters
@@ -56,7 +63,8 @@ struct RenderParams {
     CameraF64 cam64;
 };
 
-hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, hipStream_t stream);
+// resident_blocks: workgroups the device holds at once (queue mode launches no more than that)
+hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, int resident_blocks, hipStream_t stream);
 
 struct ReduceParams {
     void *accum; const void *slabs; int64_t slab_stride; int32_t chunks;
@@ -64,6 +72,8 @@ struct ReduceParams {
 };
 // accum[p] = accum[p] + slab_0[p] + slab_1[p] + ... (chunk order) for the pixels the TileMap owns
 hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream);
+// queue mode: zero the owned pixels' accumulators and the queue head
+hipError_t launch_clear(const ReduceParams &p, uint32_t *queue, hipStream_t stream);
 
 struct FinalizeParams {
     const void *accum; double *image; double *linear; // image/linear: 3 doubles per pixel

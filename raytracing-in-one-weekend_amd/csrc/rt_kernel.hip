@@ -1,25 +1,35 @@
 // gfx950 kernels of the path tracer: the loops of render_region (main.odin:510-591).
 //
 // Work decomposition
-//   wave64  = one 8x8-pixel tile, lane = pixel.  blockIdx.y = sample chunk.
-//   Every lane runs ONE flat loop whose iteration is one ray segment: the closest-hit scan
-//   over all spheres, then shading.  A lane whose path ended starts its next sample in the
-//   same iteration, so lanes never wait for the longest path of a sample; a wave ends when
-//   its slowest pixel has traced all samples of the chunk.
+//   A wave64 works on 8x8-pixel tiles.  Every lane runs ONE flat loop whose iteration is one ray
+//   segment: the closest-hit scan over all spheres, then shading.  A lane whose path ended
+//   starts another sample in the same iteration, so lanes never wait for the longest path.
+//   Throughput mode (QUEUE): work items are (tile, sample chunk) pairs behind one global
+//   counter.  A wave takes an item, deals its (pixel, sample) pairs to whichever lanes are
+//   free, and takes the next item when the pairs run out, while other lanes are still finishing
+//   paths of the previous one.  A finished sample is added to its pixel's Q32.32 accumulator in
+//   HBM with integer atomics, so the sums are exact and independent of which lane, wave or GPU
+//   traced what.  Lanes idle only when the whole queue is empty.
+//   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
+//   chunk, sums its samples in order in a register and stores the sum.
 // Closest-hit scan
-//   The sphere index is wave-uniform.  Per sphere a lane spends 3 subtractions, 3+3 fused
-//   multiply-adds for h = d.oc and |oc|^2 - r^2, and a multiply + fma for the discriminant
-//   (main.odin:245-249 with a = |d|^2 and r^2 hoisted).  Only when some lane's line
-//   meets the sphere does the wave leave the straight-line code; such a lane parks the
-//   candidate (h, disc, index) in registers and the square root / divisions / range tests of
-//   main.odin:252-261 run later, for all parked lanes at once, when a lane needs its slot
-//   again or the scan ends.  A lane's candidates are still resolved in sphere order with
-//   the shrinking t_max of main.odin:541-545, so results equal the straight loop's.
+//   The sphere index is wave-uniform: records {cx, cy, cz, r*r} come four at a time through the
+//   scalar cache into SGPRs (or from LDS), the next four being fetched while these are tested.
+//   Per sphere a lane spends 3 subtractions, 3+3 fused multiply-adds for h = d.oc and
+//   |oc|^2 - r^2, and a multiply + fma for the discriminant (main.odin:245-249 with a = |d|^2
+//   and r^2 hoisted), then one compare.  Only when some lane's line meets the sphere does the
+//   wave leave the straight-line code; such a lane parks the candidate (h, disc, index) in
+//   registers and the square root / divisions / range tests of main.odin:252-261 run later, for
+//   all parked lanes at once, when a lane needs its slot again or the scan ends.  A lane's
+//   candidates are still resolved in sphere order with the shrinking t_max of
+//   main.odin:541-545, so results equal the straight loop's.
 // Arithmetic
-//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma() calls
-//   of the F32_FMA scan.  Division and square root are IEEE correctly rounded.  Everything
-//   outside the scan follows the reference's operation order.
+//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma() calls of
+//   the F32_FMA scan.  Division and square root are IEEE correctly rounded.  Everything outside
+//   the scan follows the reference's operation order.
 #include "rt_kernel.h"
+
+#include <algorithm>
 
 namespace rtk {
 
@@ -114,51 +124,122 @@ __device__ __forceinline__ int tile_row_of(const TileMap &m, int k) {
     return ((k / m.rows_per_strip) * m.strip_count + m.strip_index) * m.rows_per_strip + (k % m.rows_per_strip);
 }
 
-template <typename Real, bool FMA, int FETCH>
+// Q32.32 fixed point of a non-negative f32 (truncated below 2^-32; NaN and negatives give 0).
+// Sums of these are exact and independent of the order of addition.
+__device__ __forceinline__ unsigned long long to_q32_32(float x) {
+    if (!(x > 0.0f)) return 0ull;
+    if (x >= 4294967296.0f) return 0xFFFFFFFF00000000ull;
+    const uint32_t hi = static_cast<uint32_t>(x);
+    const float fr = x - static_cast<float>(hi);
+    const uint32_t lo = static_cast<uint32_t>(fr * 4294967296.0f);
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; } // never used: QUEUE is f32 only
+
+// number of lanes below this one whose bit is set in `mask`
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <typename Real, bool FMA, int FETCH, bool QUEUE>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParams P) {
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
-    const int n = P.n_spheres;
+    const int n = P.n_spheres; // padded count, a multiple of GROUP
 
     extern __shared__ double4 lds_raw[];
     const R4 *rec = g_rec;
     if (FETCH == FETCH_LDS) {
         R4 *l_rec = reinterpret_cast<R4 *>(lds_raw);
-        for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
+        for (int i = threadIdx.x; i < n + GROUP; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
         __syncthreads();
         rec = l_rec;
     }
 
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (tile >= P.map.n_tiles) return; // whole wave
-    const int tx = tile % P.map.tiles_x;
-    const int ty = tile_row_of(P.map, tile / P.map.tiles_x);
-    const int u = P.min_x + tx * TILE + (lane & 7);
-    const int v = P.min_y + ty * TILE + (lane >> 3);
-    const bool inside = (u < P.max_x) && (v < P.max_y);
-
-    const uint32_t chunk = blockIdx.y;
-    uint32_t s = chunk * P.chunk_samples;                            // sample index within the call
-    const uint32_t s_end = min(P.sample_count, s + P.chunk_samples);
-    bool alive = inside && (s < s_end);
-
     const Real *C = camera_of<Real>(P);
-    const uint32_t pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
-    const uint32_t kp = mix32(P.k0 ^ pixel);
-    const uint32_t wp = mix32(P.k1 + pixel);
+
+    // ---- the work a lane is on: pixel (u, v), sample s (index within the call)
+    int u = 0, v = 0;
+    uint32_t s = 0, pixel = 0, kp = 0, wp = 0, ks = 0;
+    // literal modes: one tile and one sample chunk per wave
+    uint32_t s_end = 0;
+    bool inside = false;
+    // queue mode, all wave-uniform: the current item and its (pixel, sample) pairs
+    uint32_t pair_next = 0, pair_total = 0, npx = 0, item_s_begin = 0;
+    int x0 = 0, y0 = 0, tw = TILE;
+    bool queue_open = true;
+
+    if constexpr (!QUEUE) {
+        const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (tile >= P.map.n_tiles) return; // whole wave
+        u = P.min_x + (tile % P.map.tiles_x) * TILE + (lane & 7);
+        v = P.min_y + tile_row_of(P.map, tile / P.map.tiles_x) * TILE + (lane >> 3);
+        inside = (u < P.max_x) && (v < P.max_y);
+        s = min(P.sample_count, blockIdx.y * P.chunk_samples);
+        s_end = min(P.sample_count, s + P.chunk_samples);
+        pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
+        kp = mix32(P.k0 ^ pixel);
+        wp = mix32(P.k1 + pixel);
+    }
 
     V3<Real> ro = {Real(0), Real(0), Real(0)}, rd = {Real(0), Real(0), Real(0)}; // ray
     V3<Real> color = {Real(1), Real(1), Real(1)};                                // sample_color
-    V3<Real> acc = {Real(0), Real(0), Real(0)};                                  // pixel_color
-    uint32_t ks = 0;
+    V3<Real> acc = {Real(0), Real(0), Real(0)};                                  // pixel_color (literal modes)
     int bounce = 0;
     bool fresh = true;
-    uint32_t segments = 0;
+    uint32_t segments = 0, started = 0;
 
-    while (alive) {
+    for (;;) {
+        if constexpr (QUEUE) {
+            // Deal (pixel, sample) pairs to the lanes that need one, in lane order, taking new
+            // items from the global queue as the current one runs out.  `pending` and all queue
+            // state are wave-uniform, so this loop does not diverge.
+            unsigned long long pending = __builtin_amdgcn_ballot_w64(fresh);
+            bool got = false;
+            while (pending != 0ull) {
+                if (pair_next >= pair_total) {
+                    if (!queue_open) break;
+                    uint32_t item = 0u;
+                    if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) item = atomicAdd(P.queue, 1u); // one lane per wave
+                    item = __builtin_amdgcn_readfirstlane(item);
+                    if (item >= P.n_items) { queue_open = false; break; }
+                    const uint32_t chunk = item / static_cast<uint32_t>(P.map.n_tiles);
+                    const int tile = static_cast<int>(item % static_cast<uint32_t>(P.map.n_tiles));
+                    x0 = P.min_x + (tile % P.map.tiles_x) * TILE;
+                    y0 = P.min_y + tile_row_of(P.map, tile / P.map.tiles_x) * TILE;
+                    tw = min(TILE, P.max_x - x0);
+                    npx = static_cast<uint32_t>(tw * min(TILE, P.max_y - y0)); // pixels of the tile inside the region
+                    item_s_begin = min(P.sample_count, chunk * P.chunk_samples);
+                    pair_total = npx * (min(P.sample_count, item_s_begin + P.chunk_samples) - item_s_begin);
+                    pair_next = 0u;
+                    continue;
+                }
+                const uint32_t avail = pair_total - pair_next;
+                const bool take = fresh && !got && rank_in(pending) < avail;
+                if (take) {
+                    const uint32_t pair = pair_next + rank_in(pending);
+                    uint32_t q, si; // pixel within the tile, sample within the item
+                    if (npx == 64u) { q = pair & 63u; si = pair >> 6; } else { q = pair % npx; si = pair / npx; }
+                    s = item_s_begin + si;
+                    if (tw == TILE) { u = x0 + static_cast<int>(q & 7u); v = y0 + static_cast<int>(q >> 3); }
+                    else { u = x0 + static_cast<int>(q % static_cast<uint32_t>(tw)); v = y0 + static_cast<int>(q / static_cast<uint32_t>(tw)); }
+                    pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
+                    kp = mix32(P.k0 ^ pixel);
+                    wp = mix32(P.k1 + pixel);
+                    got = true;
+                }
+                const unsigned long long taken = __builtin_amdgcn_ballot_w64(take);
+                pair_next += static_cast<uint32_t>(__builtin_popcountll(taken));
+                pending &= ~taken;
+            }
+            if (fresh && !got) break; // the queue is empty: this lane is done
+        } else {
+            if (fresh && !(inside && s < s_end)) break;
+        }
         if (fresh) {
             // camera ray of global sample sample_begin + s (main.odin:519-534)
+            ++started;
             ks = mix32(kp + 0x9e3779b9u * (P.sample_begin + s + 1u));
             Draws g(ks, wp, 0u);
             Real jx = g.range<Real>(Real(-0.5), Real(0.5));
@@ -202,10 +283,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
             if (!rejected && root < closest) { closest = root; hit = pend; }
             pend = -1;
         };
-
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
-            const R4 sp = rec[i];
+        auto test = [&](const R4 sp, const int i) {
             const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
             Real h, cc, disc;
             if (FMA) {
@@ -226,6 +304,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
                 }
                 if (cand) { pend_h = h; pend_disc = disc; pend = i; }
             }
+        };
+        // The record array is padded to a multiple of GROUP with records that can never be hit
+        // (r*r = -inf) plus one more group, so the next group is always loadable while the
+        // current one is tested.
+        R4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+        for (int i = 0; i < n; i += GROUP) {
+            const R4 p0 = rec[i + 4], p1 = rec[i + 5], p2 = rec[i + 6], p3 = rec[i + 7];
+            test(c0, i); test(c1, i + 1); test(c2, i + 2); test(c3, i + 3);
+            c0 = p0; c1 = p1; c2 = p2; c3 = p3;
         }
         if (pend >= 0) resolve();
         ++segments;
@@ -265,8 +352,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
                     // Schlick (main.odin:111-122); the uniform is drawn only on this branch (:390)
                     Real r0 = (Real(1) - rel) / (Real(1) + rel);
                     r0 *= r0;
-                    const Real q = Real(1) - cos_theta;
-                    const Real refl = r0 + (Real(1) - r0) * q * q * q * q * q;
+                    const Real qq = Real(1) - cos_theta;
+                    const Real refl = r0 + (Real(1) - r0) * qq * qq * qq * qq * qq;
                     do_reflect = refl > g.next<Real>();
                 }
                 dir = do_reflect ? reflect(unit, nrm) : refract(unit, nrm, rel);
@@ -304,35 +391,47 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
             ended = true;
         }
         if (ended) {
-            acc = acc + color; // main.odin:575
-            ++s;
+            // pixel_color += sample_color (main.odin:575)
+            if constexpr (QUEUE) {
+                unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * 3;
+                atomicAdd(dst + 0, to_q32_32(color.x));
+                atomicAdd(dst + 1, to_q32_32(color.y));
+                atomicAdd(dst + 2, to_q32_32(color.z));
+            } else {
+                acc = acc + color;
+                ++s;
+            }
             fresh = true;
-            alive = s < s_end;
         }
     }
 
-    if (inside) {
-        Real *out = (chunk == 0 ? static_cast<Real *>(P.accum) : static_cast<Real *>(P.slabs) + static_cast<int64_t>(chunk - 1) * P.slab_stride) +
-                    static_cast<int64_t>(pixel) * 3;
-        out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+    if constexpr (!QUEUE) {
+        if (inside) {
+            const uint32_t chunk = blockIdx.y;
+            Real *out = (chunk == 0 ? static_cast<Real *>(P.accum) : static_cast<Real *>(P.slabs) + static_cast<int64_t>(chunk - 1) * P.slab_stride) +
+                        static_cast<int64_t>(pixel) * 3;
+            out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+        }
     }
     if (P.stats != nullptr) {
-        // wave totals: segments traced and camera rays started
-        uint32_t seg = segments;
-        uint32_t smp = inside ? (s_end > chunk * P.chunk_samples ? s_end - chunk * P.chunk_samples : 0u) : 0u;
+        // wave totals: segments traced, camera rays started, and the wave's loop trip count
+        // (a lane that is alive in every iteration exists in both modes: the last to finish)
+        uint32_t seg = segments, iters = segments, smp = started;
         for (int off = 32; off > 0; off >>= 1) {
             seg += __shfl_xor(seg, off, 64);
             smp += __shfl_xor(smp, off, 64);
+            iters = max(iters, static_cast<uint32_t>(__shfl_xor(iters, off, 64)));
         }
         if (lane == 0) {
             atomicAdd(&P.stats[0], static_cast<unsigned long long>(seg));
             atomicAdd(&P.stats[3], static_cast<unsigned long long>(smp));
+            atomicAdd(&P.stats[4], static_cast<unsigned long long>(iters));
         }
     }
 }
 
 // ----------------------------------------------------------------------------- small kernels
-// thread -> owned pixel: the same tile enumeration as render_kernel, 64 pixels per tile
+// thread -> owned pixel: the tile enumeration of render_kernel, 64 pixels per tile
 __device__ __forceinline__ bool owned_pixel(const TileMap &m, int min_x, int min_y, int max_x, int max_y, int width, int64_t &index) {
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int tile = static_cast<int>(gid >> 6);
@@ -345,6 +444,16 @@ __device__ __forceinline__ bool owned_pixel(const TileMap &m, int min_x, int min
     return true;
 }
 
+// zero the Q32.32 accumulators of the owned pixels and the queue head, ahead of a queue-mode launch
+__global__ void clear_kernel(const ReduceParams P, uint32_t *queue) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queue = 0u;
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    unsigned long long *a = static_cast<unsigned long long *>(P.accum) + idx * 3;
+    a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
+}
+
+// literal modes: accum[p] += slab_0[p] + slab_1[p] + ... in chunk order
 template <typename Real> __global__ void reduce_kernel(const ReduceParams P) {
     int64_t idx;
     if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
@@ -374,45 +483,74 @@ template <typename Real> __global__ void finalize_kernel(const FinalizeParams P)
     P.image[idx * 3 + 2] = static_cast<double>(sqrt_rn(mz));
 }
 
+// The same tail for Q32.32 sums, in f64: u64 -> f64 with one rounding, * 2^-32, * 1/spp, sqrt.
+__device__ __forceinline__ double q32_32_to_f64(unsigned long long v) {
+    return static_cast<double>(static_cast<uint32_t>(v >> 32)) * 4294967296.0 + static_cast<double>(static_cast<uint32_t>(v));
+}
+__global__ void finalize_q_kernel(const FinalizeParams P) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    const unsigned long long *in = static_cast<const unsigned long long *>(P.accum) + idx * 3;
+    const double contribution = 1.0 / static_cast<double>(P.total_samples);
+    for (int c = 0; c < 3; ++c) {
+        const double mean = (q32_32_to_f64(in[c]) * (1.0 / 4294967296.0)) * contribution;
+        if (P.linear != nullptr) P.linear[idx * 3 + c] = mean;
+        P.image[idx * 3 + c] = sqrt_rn(mean);
+    }
+}
+
 // ----------------------------------------------------------------------------- launchers
-template <typename Real, bool FMA>
-static hipError_t launch_render_t(const RenderParams &p, int fetch, int chunks, hipStream_t stream) {
+template <class K> static void launch_k(K kernel, dim3 grid, int fetch, int n_records, size_t rec_bytes, hipStream_t stream, const RenderParams &p) {
+    const size_t lds = fetch == FETCH_LDS ? static_cast<size_t>(n_records + GROUP) * rec_bytes : 0;
+    hipLaunchKernelGGL(kernel, grid, dim3(BLOCK_THREADS, 1, 1), lds, stream, p);
+}
+
+hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, int resident_blocks, hipStream_t stream) {
+    if (p.map.n_tiles <= 0 || chunks <= 0) return hipSuccess;
     const int blocks = (p.map.n_tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    if (blocks <= 0 || chunks <= 0) return hipSuccess;
-    dim3 grid(blocks, chunks, 1), block(BLOCK_THREADS, 1, 1);
-    if (fetch == FETCH_LDS) {
-        size_t lds = static_cast<size_t>(p.n_spheres) * sizeof(typename Rec4<Real>::type);
-        hipLaunchKernelGGL((render_kernel<Real, FMA, FETCH_LDS>), grid, block, lds, stream, p);
-    } else {
-        hipLaunchKernelGGL((render_kernel<Real, FMA, FETCH_SCALAR>), grid, block, 0, stream, p);
+    const bool lds = fetch == FETCH_LDS;
+    switch (arith) {
+    case ARITH_F32_FMA: {
+        // queue mode: as many workgroups as the chip holds at once (or fewer if the work is smaller)
+        const int64_t waves_needed = static_cast<int64_t>(p.n_items);
+        const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (waves_needed + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
+        if (lds) launch_k(render_kernel<float, true, FETCH_LDS, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
+        else launch_k(render_kernel<float, true, FETCH_SCALAR, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
+        break;
+    }
+    case ARITH_F64:
+        if (lds) launch_k(render_kernel<double, false, FETCH_LDS, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(double4), stream, p);
+        else launch_k(render_kernel<double, false, FETCH_SCALAR, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(double4), stream, p);
+        break;
+    case ARITH_F32_LITERAL:
+        if (lds) launch_k(render_kernel<float, false, FETCH_LDS, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
+        else launch_k(render_kernel<float, false, FETCH_SCALAR, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
+        break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks, hipStream_t stream) {
-    switch (arith) {
-    case ARITH_F32_FMA: return launch_render_t<float, true>(p, fetch, chunks, stream);
-    case ARITH_F64: return launch_render_t<double, false>(p, fetch, chunks, stream);
-    case ARITH_F32_LITERAL: return launch_render_t<float, false>(p, fetch, chunks, stream);
-    default: return hipErrorInvalidValue;
-    }
+static dim3 pixel_grid(const TileMap &m) { return dim3(static_cast<unsigned>((static_cast<int64_t>(m.n_tiles) * 64 + 255) / 256)); }
+
+hipError_t launch_clear(const ReduceParams &p, uint32_t *queue, hipStream_t stream) {
+    if (p.map.n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(clear_kernel, pixel_grid(p.map), dim3(256), 0, stream, p, queue);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
-    const int64_t threads = static_cast<int64_t>(p.map.n_tiles) * 64;
-    if (threads <= 0 || p.chunks <= 1) return hipSuccess;
-    dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
-    if (arith == ARITH_F64) hipLaunchKernelGGL(reduce_kernel<double>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(reduce_kernel<float>, grid, block, 0, stream, p);
+    if (p.map.n_tiles <= 0 || p.chunks <= 1 || arith == ARITH_F32_FMA) return hipSuccess;
+    if (arith == ARITH_F64) hipLaunchKernelGGL(reduce_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(reduce_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream) {
-    const int64_t threads = static_cast<int64_t>(p.map.n_tiles) * 64;
-    if (threads <= 0) return hipSuccess;
-    dim3 grid(static_cast<unsigned>((threads + 255) / 256)), block(256);
-    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_kernel<double>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(finalize_kernel<float>, grid, block, 0, stream, p);
+    if (p.map.n_tiles <= 0) return hipSuccess;
+    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_q_kernel, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(finalize_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -48,12 +48,18 @@ def test_bitwise_vs_oracle(rt, oracle, name, width, spp, precision):
 
 
 @pytest.mark.parametrize("chunks", [2, 3, 5])
-def test_sample_chunks_match_oracle_chunked_sum(rt, oracle, chunks):
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_sample_chunks_match_oracle_chunked_sum(rt, oracle, chunks, precision):
+    # f32 throughput mode sums exactly (Q32.32), so chunking cannot change it; the two
+    # literal modes add chunk sums in chunk order, which the oracle mirrors
     cs, cam, sph, mat = scene(rt, "dev", 48, 10)
     w, h = cs.image_width, cs.image_height
-    image, linear, _ = gpu_render(rt, cs, cam, sph, mat, seed=3, sample_chunks=chunks)
-    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=3, sample_chunks=chunks)
+    image, linear, _ = gpu_render(rt, cs, cam, sph, mat, seed=3, sample_chunks=chunks, precision=precision)
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=3, sample_chunks=chunks)
     assert np.array_equal(image, ref["image"])
+    if precision == 0:
+        one = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=3, sample_chunks=1)
+        assert np.array_equal(image, one["image"])
 
 
 def test_lds_fetch_equals_scalar_fetch(rt):
@@ -131,13 +137,13 @@ def test_device_resident_strips_and_sample_split(rt, oracle):
     w, h = cs.image_width, cs.image_height
     world = rt.World(sph, mat)
     dev = torch.device("cuda:0")
-    full = torch.zeros(h, w, 3, dtype=torch.float32, device=dev)
+    full = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums of the f32 throughput mode
     world.render_accumulate(cam, w, h, full.data_ptr(), seed=8, sample_chunks=1)
     torch.cuda.synchronize()
     ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=8)
     assert np.array_equal(full.cpu().numpy().astype(np.float64), ref["accum"])
     # row strips dealt over 3 "ranks" tile the image exactly
-    parts = torch.full((h, w, 3), -1.0, dtype=torch.float32, device=dev)
+    parts = torch.full((h, w, 3), -1, dtype=torch.int64, device=dev)
     for r in range(3):
         world.render_accumulate(cam, w, h, parts.data_ptr(), seed=8, strip_rows=16, strip_index=r, strip_count=3, sample_chunks=1)
     torch.cuda.synchronize()
@@ -152,6 +158,7 @@ def test_device_resident_strips_and_sample_split(rt, oracle):
     rb = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=8, sample_begin=2, sample_count=4)
     assert np.array_equal(a.cpu().numpy().astype(np.float64), ra["accum"])
     assert np.array_equal(b.cpu().numpy().astype(np.float64), rb["accum"])
+    assert torch.equal(a + b, full)  # exact sums: any split of the samples adds up to the same accumulators
     # finalize on the device
     img = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
     world.finalize(full.data_ptr(), w, h, 6, img.data_ptr())
