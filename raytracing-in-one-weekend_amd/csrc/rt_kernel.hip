@@ -147,14 +147,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of GROUP
 
+    // The records never change during a launch.  Reading them through the constant address
+    // space tells the compiler so: a wave-uniform index then becomes a scalar-cache load into
+    // SGPRs even though the kernel also writes global memory (its atomics and stores would
+    // otherwise make every such load a per-lane vector load).
+    typedef const Real __attribute__((address_space(4))) *ConstReal;
+    ConstReal c_rec = (ConstReal)(P.sphere_rec);
     extern __shared__ double4 lds_raw[];
-    const R4 *rec = g_rec;
+    R4 *l_rec = reinterpret_cast<R4 *>(lds_raw);
     if (FETCH == FETCH_LDS) {
-        R4 *l_rec = reinterpret_cast<R4 *>(lds_raw);
         for (int i = threadIdx.x; i < n + GROUP; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
         __syncthreads();
-        rec = l_rec;
     }
+    auto rec = [&](int i) -> R4 {
+        if constexpr (FETCH == FETCH_LDS) return l_rec[i];
+        else { R4 r; r.x = c_rec[4 * i]; r.y = c_rec[4 * i + 1]; r.z = c_rec[4 * i + 2]; r.w = c_rec[4 * i + 3]; return r; }
+    };
 
     const int lane = threadIdx.x & 63;
     const Real *C = camera_of<Real>(P);
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
         // The record array is padded to a multiple of GROUP with records that can never be hit
         // (r*r = -inf) plus one more group, so the next group is always loadable while the
         // current one is tested.
-        R4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+        R4 c0 = rec(0), c1 = rec(1), c2 = rec(2), c3 = rec(3);
         for (int i = 0; i < n; i += GROUP) {
-            const R4 p0 = rec[i + 4], p1 = rec[i + 5], p2 = rec[i + 6], p3 = rec[i + 7];
+            const R4 p0 = rec(i + 4), p1 = rec(i + 5), p2 = rec(i + 6), p3 = rec(i + 7);
             test(c0, i); test(c1, i + 1); test(c2, i + 2); test(c3, i + 3);
             c0 = p0; c1 = p1; c2 = p2; c3 = p3;
         }
