@@ -163,9 +163,10 @@ int auto_chunks(int32_t n_tiles, int64_t sample_count) {
 }
 
 int auto_queue_chunks(int64_t sample_count) {
-    // work items of about 16 samples per pixel: small enough that the items still running when
-    // the queue empties are a sliver of the launch, large enough that taking one is free
-    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + 15) / 16, 4096)));
+    // work items of about 4 samples per pixel (256 paths): small enough that the items still
+    // running when the queue empties are a sliver of the launch, large enough that taking one
+    // (an atomic and a few scalar instructions per wave) costs nothing
+    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + 3) / 4, 4096)));
 }
 
 std::atomic<uint64_t> g_call_counter{0};

@@ -49,6 +49,9 @@ __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// IEEE maxNum: a NaN operand is ignored (v_max_f32 / v_max_f64)
+__device__ __forceinline__ float max_num(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double max_num(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ float abs_rn(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_rn(double x) { return __builtin_fabs(x); }
 template <typename Real> __device__ __forceinline__ Real min_std(Real a, Real b) { return (b < a) ? b : a; } // std::min
@@ -291,18 +294,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
             if (!rejected && root < closest) { closest = root; hit = pend; }
             pend = -1;
         };
-        auto test = [&](const R4 sp, const int i) {
+        // discriminant of main.odin:245-249 for one sphere; also yields h and c
+        auto discriminant = [&](const R4 sp, Real &h, Real &cc) -> Real {
             const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
-            Real h, cc, disc;
             if (FMA) {
                 h = fma_rn(rd.z, ocz, fma_rn(rd.y, ocy, rd.x * ocx));
                 cc = fma_rn(ocz, ocz, fma_rn(ocy, ocy, fma_rn(ocx, ocx, -sp.w)));
-                disc = fma_rn(h, h, -(a * cc));
+                return fma_rn(h, h, -(a * cc));
             } else {
                 h = rd.x * ocx + rd.y * ocy + rd.z * ocz;
                 cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
-                disc = h * h - a * cc;
+                return h * h - a * cc;
             }
+        };
+        // the uncommon continuation for one sphere: some lane's line meets it
+        auto park = [&](const Real h, const Real cc, const Real disc, const int i) {
             if (__builtin_amdgcn_ballot_w64(disc >= Real(0)) != 0ull) {
                 // A line that meets the sphere only behind the origin (h <= 0) while the origin
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
@@ -315,11 +321,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
         };
         // The record array is padded to a multiple of GROUP with records that can never be hit
         // (r*r = -inf) plus one more group, so the next group is always loadable while the
-        // current one is tested.
+        // current one is tested.  One compare covers the group: the largest of the four
+        // discriminants (NaNs ignored) is negative in every lane for most groups.
         R4 c0 = rec(0), c1 = rec(1), c2 = rec(2), c3 = rec(3);
         for (int i = 0; i < n; i += GROUP) {
             const R4 p0 = rec(i + 4), p1 = rec(i + 5), p2 = rec(i + 6), p3 = rec(i + 7);
-            test(c0, i); test(c1, i + 1); test(c2, i + 2); test(c3, i + 3);
+            Real h0, h1, h2, h3, k0, k1, k2, k3;
+            const Real d0 = discriminant(c0, h0, k0), d1 = discriminant(c1, h1, k1);
+            const Real d2 = discriminant(c2, h2, k2), d3 = discriminant(c3, h3, k3);
+            const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {
+                park(h0, k0, d0, i); park(h1, k1, d1, i + 1); park(h2, k2, d2, i + 2); park(h3, k3, d3, i + 3);
+            }
             c0 = p0; c1 = p1; c2 = p2; c3 = p3;
         }
         if (pend >= 0) resolve();
