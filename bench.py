@@ -72,6 +72,7 @@ def main():
     import torch
     import torch.distributed as dist
     rt = importlib.import_module("raytracing-in-one-weekend_amd")
+    multi_gpu = importlib.import_module("raytracing-in-one-weekend_amd.multi_gpu")
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,24 +103,20 @@ def main():
     stats = torch.zeros(rt.STATS_COUNT, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     by_samples = args.partition == "samples"
-    total_spp = args.spp * world_size if by_samples else args.spp
+
+    plan = multi_gpu.Plan(args.partition, rank, world_size, args.spp)
+    collect = {"stats": False}
+
+    def trace(buf, **kw):
+        world.render_accumulate(cam, w, h, buf.data_ptr(), seed=1, sphere_fetch=fetch, sample_chunks=args.chunks,
+                                d_stats=stats.data_ptr() if collect["stats"] else 0, stream=stream, **kw)
+
+    def finish(buf, img, total_samples, **kw):
+        world.finalize(buf.data_ptr(), w, h, total_samples, img.data_ptr(), stream=stream, **kw)
 
     def step(collect_stats=False):
-        if by_samples:
-            world.render_accumulate(cam, w, h, accum.data_ptr(), sample_begin=rank * args.spp, sample_count=args.spp, seed=1,
-                                    sphere_fetch=fetch, sample_chunks=args.chunks, d_stats=stats.data_ptr() if collect_stats else 0, stream=stream)
-            if world_size > 1:
-                dist.all_reduce(accum, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                world.finalize(accum.data_ptr(), w, h, total_spp, image.data_ptr(), stream=stream)
-        else:
-            world.render_accumulate(cam, w, h, accum.data_ptr(), strip_rows=8, strip_index=rank, strip_count=world_size, sample_count=args.spp,
-                                    seed=1, sphere_fetch=fetch, sample_chunks=args.chunks, d_stats=stats.data_ptr() if collect_stats else 0, stream=stream)
-            world.finalize(accum.data_ptr(), w, h, total_spp, image.data_ptr(), strip_rows=8, strip_index=rank, strip_count=world_size, stream=stream)
-            if world_size > 1:
-                # rank 0 gathers the strips: every rank's image is zero outside its own strips
-                gathered.copy_(image)
-                dist.reduce(gathered, dst=0, op=dist.ReduceOp.SUM)
+        collect["stats"] = collect_stats
+        return multi_gpu.render_step(plan, dist, accum, image, gathered, trace, finish)
 
     def fence():
         torch.cuda.synchronize()
@@ -152,6 +149,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
+    total_spp = plan.total_spp
     samples_step = w * h * total_spp
     value = samples_step * args.steps / elapsed / 1e6
 

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "librt_mi355x.so")  # env override: A/B builds of the library
 
 # ---- constants of include/rt_mi355x.h ------------------------------------------------
 RT_OK = 0

@@ -144,8 +144,14 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU_ATTR
+#else
+#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+#endif
+
 template <typename Real, bool FMA, int FETCH, bool QUEUE>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of GROUP
@@ -321,18 +327,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParam
         };
         // The record array is padded to a multiple of GROUP with records that can never be hit
         // (r*r = -inf) plus one more group, so the next group is always loadable while the
-        // current one is tested.  One compare covers the group: the largest of the four
+        // current one is tested.  One compare covers a group: the largest of the four
         // discriminants (NaNs ignored) is negative in every lane for most groups.
-        R4 c0 = rec(0), c1 = rec(1), c2 = rec(2), c3 = rec(3);
-        for (int i = 0; i < n; i += GROUP) {
-            const R4 p0 = rec(i + 4), p1 = rec(i + 5), p2 = rec(i + 6), p3 = rec(i + 7);
+        auto test_group = [&](const R4 &s0, const R4 &s1, const R4 &s2, const R4 &s3, const int i) {
             Real h0, h1, h2, h3, k0, k1, k2, k3;
-            const Real d0 = discriminant(c0, h0, k0), d1 = discriminant(c1, h1, k1);
-            const Real d2 = discriminant(c2, h2, k2), d3 = discriminant(c3, h3, k3);
+            const Real d0 = discriminant(s0, h0, k0), d1 = discriminant(s1, h1, k1);
+            const Real d2 = discriminant(s2, h2, k2), d3 = discriminant(s3, h3, k3);
             const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {
                 park(h0, k0, d0, i); park(h1, k1, d1, i + 1); park(h2, k2, d2, i + 2); park(h3, k3, d3, i + 3);
             }
+        };
+        R4 c0 = rec(0), c1 = rec(1), c2 = rec(2), c3 = rec(3);
+        for (int i = 0; i < n; i += GROUP) {
+            const R4 p0 = rec(i + 4), p1 = rec(i + 5), p2 = rec(i + 6), p3 = rec(i + 7);
+            test_group(c0, c1, c2, c3, i);
             c0 = p0; c1 = p1; c2 = p2; c3 = p3;
         }
         if (pend >= 0) resolve();

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/.  Run from the repo root: python tests/golden/make_golden.py
+
+rng_kat.json            counter-RNG known answers, computed by the pure-Python restatement (tests/pyref.py)
+render_<scene>_f64.npz  32x18, 4 spp gamma image + linear means of BASELINE configs 1 ("two") and 2 ("dev"),
+                        computed by tests/pyref.py in IEEE f64 -- independent of the C++ oracle and of the GPU
+render_<scene>_f32.npz  the same renders in the two f32 arithmetics, computed by the C++ oracle (regression pins)
+intersection_kat.json   ray_sphere_intersection cases with closed-form answers
+No reference source or reference output is involved: the reference ships no vectors for this path.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pyref  # noqa: E402
+import oracle_lib  # noqa: E402
+
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+SEED = 20250912
+W, SPP = 32, 4
+
+
+def cam_dict(cam):
+    d = {}
+    for name, _ in cam._fields_:
+        v = getattr(cam, name)
+        d[name] = v.tuple() if hasattr(v, "tuple") else v
+    return d
+
+
+def main():
+    kat = []
+    for seed, pixel, sample, bounce, draw in [(0, 0, 0, 0, 0), (1, 2, 3, 4, 5), (SEED, 809999, 499, 50, 7), (2**64 - 1, 2**32 - 1, 2**32 - 3, 51, 191),
+                                              (0x0123456789ABCDEF, 12345, 67, 8, 9), (42, 0, 0, 1, 0), (42, 1, 0, 0, 0), (42, 0, 1, 0, 0)]:
+        kat.append({"seed": seed, "pixel": pixel, "sample": sample, "bounce": bounce, "draw": draw, "u32": pyref.rng_u32(seed, pixel, sample, bounce, draw)})
+    json.dump(kat, open(os.path.join(HERE, "rng_kat.json"), "w"), indent=1)
+
+    o = oracle_lib.Oracle()
+    for name, build in (("two", rt.build_two_sphere_scene), ("dev", rt.build_dev_scene)):
+        cs, sph, mat = build(W)
+        cs.samples_per_pixel = SPP
+        cam = rt.calculate_camera_render_data(cs)
+        w, h = cs.image_width, cs.image_height
+        spl = [(tuple(s["center"]), float(s["radius"]), int(s["material_index"])) for s in sph]
+        ml = [(int(m["type"]), tuple(m["albedo"]), float(m["param1"])) for m in mat]
+        gam, seg = pyref.render_region(w, h, (0, 0, w, h), cam_dict(cam), spl, ml, SEED)
+        lin, _ = pyref.render_region(w, h, (0, 0, w, h), cam_dict(cam), spl, ml, SEED, want_linear=True)
+        image = np.array([[gam[(u, v)] for u in range(w)] for v in range(h)])
+        linear = np.array([[lin[(u, v)] for u in range(w)] for v in range(h)])
+        np.savez_compressed(os.path.join(HERE, f"render_{name}_f64.npz"), image=image, linear=linear, segments=np.int64(seg),
+                            seed=np.uint64(SEED), spp=np.int64(SPP), width=np.int64(w), height=np.int64(h))
+        out = {}
+        for label, precision in (("fma", rt.PRECISION_F32), ("literal", rt.PRECISION_F32_LITERAL)):
+            r = o.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=SEED)
+            out[f"image_{label}"] = r["image"]
+            out[f"linear_{label}"] = r["linear"]
+            out[f"segments_{label}"] = np.int64(r["stats"][0])
+        np.savez_compressed(os.path.join(HERE, f"render_{name}_f32.npz"), seed=np.uint64(SEED), spp=np.int64(SPP), **out)
+        print(name, w, h, "segments", seg)
+
+    # ray_sphere_intersection: closed-form cases (origin, direction, centre, radius, t_min, t_max) -> t
+    cases = [
+        # head-on, unit direction: near root 4
+        dict(o=[0, 0, 0], d=[0, 0, -1], c=[0, 0, -5], r=1, t_min=0.001, t_max=1e30, t=4.0, note="near root"),
+        # non-unit direction (length 2): roots halve
+        dict(o=[0, 0, 0], d=[0, 0, -2], c=[0, 0, -5], r=1, t_min=0.001, t_max=1e30, t=2.0, note="t is in units of |d|"),
+        # miss: line passes 2 away from a radius-1 sphere
+        dict(o=[0, 2, 0], d=[0, 0, -1], c=[0, 0, -5], r=1, t_min=0.001, t_max=123.0, t=123.0, note="miss returns t_max"),
+        # tangent: discriminant exactly 0, single root 5
+        dict(o=[0, 1, 0], d=[0, 0, -1], c=[0, 0, -5], r=1, t_min=0.001, t_max=1e30, t=5.0, note="tangent"),
+        # origin inside the sphere: near root negative, far root 1
+        dict(o=[0, 0, 0], d=[1, 0, 0], c=[0, 0, 0], r=1, t_min=0.001, t_max=1e30, t=1.0, note="inside: far root"),
+        # near root below t_min (origin on the surface), far root 2
+        dict(o=[-1, 0, 0], d=[1, 0, 0], c=[0, 0, 0], r=1, t_min=0.001, t_max=1e30, t=2.0, note="near root < t_min"),
+        # both roots beyond t_max
+        dict(o=[0, 0, 0], d=[0, 0, -1], c=[0, 0, -5], r=1, t_min=0.001, t_max=3.5, t=3.5, note="t_max <= root"),
+        # t_max equal to the near root: the interval is half open, so rejected; far root 6 also >= t_max
+        dict(o=[0, 0, 0], d=[0, 0, -1], c=[0, 0, -5], r=1, t_min=0.001, t_max=4.0, t=4.0, note="t_max == root is rejected"),
+        # sphere behind the origin
+        dict(o=[0, 0, 0], d=[0, 0, 1], c=[0, 0, -5], r=1, t_min=0.001, t_max=77.0, t=77.0, note="behind"),
+        # negative radius behaves as its absolute value in the intersection (r*r)
+        dict(o=[0, 0, 0], d=[0, 0, -1], c=[0, 0, -5], r=-1, t_min=0.001, t_max=1e30, t=4.0, note="r*r"),
+    ]
+    json.dump(cases, open(os.path.join(HERE, "intersection_kat.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

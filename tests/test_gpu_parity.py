@@ -194,3 +194,27 @@ def test_stochastic_mode_differs_between_calls(rt):
     a, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=1, rng_mode=rt.RNG_STOCHASTIC)
     b, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=1, rng_mode=rt.RNG_STOCHASTIC)
     assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["two", "dev"])
+def test_against_committed_golden_fixtures(rt, name):
+    """GPU against tests/golden: the f64 fixtures come from the pure-Python restatement of the
+    reference (no C++ oracle, no GPU involved in making them), the f32 ones from the oracle."""
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g64 = np.load(os.path.join(golden, f"render_{name}_f64.npz"))
+    g32 = np.load(os.path.join(golden, f"render_{name}_f32.npz"))
+    cs, cam, sph, mat = scene(rt, name, int(g64["width"]), int(g64["spp"]))
+    seed = int(g64["seed"])
+    image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=rt.PRECISION_F64)
+    assert np.array_equal(image, g64["image"]) and np.array_equal(linear, g64["linear"])
+    assert int(stats[0]) == int(g64["segments"])
+    for label, precision in (("fma", rt.PRECISION_F32), ("literal", rt.PRECISION_F32_LITERAL)):
+        image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=precision)
+        assert np.array_equal(image, g32[f"image_{label}"])
+        assert int(stats[0]) == int(g32[f"segments_{label}"])
+    # the spec's criteria, f32 throughput mode against the f64 fixture
+    image, linear, _ = gpu_render(rt, cs, cam, sph, mat, seed=seed)
+    rel = np.abs(linear - g64["linear"]) / np.maximum(g64["linear"], 1e-3)
+    assert np.mean(rel.max(axis=2) <= 1e-4) > 0.97
+    assert np.mean(np.all(rt.quantize_rgb8(image) == rt.quantize_rgb8(g64["image"]), axis=2)) > 0.97

@@ -1,0 +1,217 @@
+"""The CPU oracle against its pins (no GPU).
+
+The reference holds no golden vectors for this path, so the pins are: a second, independent
+Python restatement of the reference (tests/pyref.py), fixtures generated from it
+(tests/golden/*_f64.npz, rng_kat.json), closed-form intersection cases, and analytic scenes.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import pyref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def as_lists(sph, mat):
+    spl = [(tuple(s["center"]), float(s["radius"]), int(s["material_index"])) for s in sph]
+    ml = [(int(m["type"]), tuple(m["albedo"]), float(m["param1"])) for m in mat]
+    return spl, ml
+
+
+def cam_dict(cam):
+    d = {}
+    for name, _ in cam._fields_:
+        v = getattr(cam, name)
+        d[name] = v.tuple() if hasattr(v, "tuple") else v
+    return d
+
+
+def test_rng_known_answers(rt, oracle):
+    kat = json.load(open(os.path.join(GOLDEN, "rng_kat.json")))
+    assert len(kat) >= 8
+    for k in kat:
+        args = (k["seed"], k["pixel"], k["sample"], k["bounce"], k["draw"])
+        assert oracle.rng_u32(*args) == k["u32"]
+        assert rt.rng_u32(*args) == k["u32"]      # the product's host-side statement of the same RNG
+        assert pyref.rng_u32(*args) == k["u32"]
+
+
+def test_rng_streams_are_distinct_and_uniform(oracle):
+    # neighbouring keys give unrelated draws; the top 24 bits are uniform enough for a chi-square over 16 bins
+    vals = np.array([oracle.rng_u32(7, p, s, b, d) for p in range(8) for s in range(8) for b in range(4) for d in range(8)], dtype=np.uint64)
+    assert len(set(vals.tolist())) == len(vals)
+    u = (vals >> 8).astype(np.float64) / 2**24
+    hist, _ = np.histogram(u, bins=16, range=(0, 1))
+    chi2 = float(((hist - len(u) / 16) ** 2 / (len(u) / 16)).sum())
+    assert chi2 < 50.0  # 15 degrees of freedom: P(chi2 > 50) ~ 1e-5
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_intersection_closed_form(rt, oracle, precision):
+    cases = json.load(open(os.path.join(GOLDEN, "intersection_kat.json")))
+    for c in cases:
+        t = oracle.ray_sphere_intersection(precision, c["o"], c["d"], c["c"], c["r"], c["t_min"], c["t_max"])
+        want = c["t"] if precision == 1 else float(np.float32(c["t"]))
+        assert t == want, c["note"]
+        if precision == 1:
+            assert pyref.ray_sphere_intersection(tuple(c["o"]), tuple(c["d"]), tuple(c["c"]), c["r"], c["t_min"], c["t_max"]) == c["t"], c["note"]
+
+
+def test_intersection_random_against_pyref(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        o, d, c = rng.normal(size=3), rng.normal(size=3), rng.normal(size=3) * 2
+        r = float(rng.uniform(0.1, 2.0))
+        tmax = float(rng.choice([1e300, 1.5, 3.0]))
+        a = oracle.ray_sphere_intersection(1, o, d, c, r, 0.001, tmax)
+        b = pyref.ray_sphere_intersection(tuple(o), tuple(d), tuple(c), r, 0.001, tmax)
+        assert a == b
+
+
+MATERIAL_CASES = [
+    ("lambertian", (0, (0.8, 0.6, 0.2), 0.0), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
+    ("metal fuzz 0", (1, (0.7, 0.6, 0.5), 0.0), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
+    ("metal fuzz 1 grazing (may absorb)", (1, (0.8, 0.6, 0.2), 1.0), (1.0, -0.05, 0.0), (0.0, 1.0, 0.0), True),
+    ("glass front face", (2, (0.0, 0.0, 0.0), 1.5), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
+    ("glass back face, steep: total internal reflection", (2, (0.0, 0.0, 0.0), 1.5), (1.0, -0.2, 0.0), (0.0, 1.0, 0.0), False),
+    ("glass back face, shallow: refracts or reflects", (2, (0.0, 0.0, 0.0), 1.5), (0.1, -1.0, 0.0), (0.0, 1.0, 0.0), False),
+    ("air bubble ri < 1", (2, (0.0, 0.0, 0.0), 1.0 / 1.5), (0.2, -1.0, 0.1), (0.0, 1.0, 0.0), True),
+    ("air bubble back face", (2, (0.0, 0.0, 0.0), 1.0 / 1.5), (0.9, -0.3, 0.1), (0.0, 1.0, 0.0), False),
+]
+
+
+@pytest.mark.parametrize("name,material,ray_d,normal,front", MATERIAL_CASES)
+def test_scatter_against_pyref(oracle, name, material, ray_d, normal, front):
+    hit_p = (0.5, 0.25, -1.0)
+    ray_o = (0.0, 2.0, 0.0)
+    absorbed = 0
+    for sample in range(40):
+        keys = (99, 1234, sample, 3)
+        o_, d_, att, ok = oracle.material_scatter(1, material, ray_o, ray_d, hit_p, normal, front, *keys)
+        (po, pd), patt, pok = pyref.material_scatter(material, ray_o, ray_d, hit_p, normal, front, pyref.Gen(*keys))
+        assert ok == pok, name
+        assert tuple(o_) == po and tuple(d_) == pd and tuple(att) == patt, name
+        absorbed += not ok
+    if material[0] != 1:
+        assert absorbed == 0  # only metal can absorb (main.odin:351)
+
+
+def test_total_internal_reflection_draws_nothing(oracle):
+    # steep back-face hit in glass: must_reflect short-circuits the uniform draw (main.odin:390), so the
+    # outcome cannot depend on the stream
+    material = (2, (0.0, 0.0, 0.0), 1.5)
+    outs = {tuple(oracle.material_scatter(1, material, (0, 2, 0), (1.0, -0.2, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), False, 5, 6, s, 1)[1]) for s in range(16)}
+    assert len(outs) == 1
+    d = next(iter(outs))
+    unit = np.array((1.0, -0.2, 0.0)) / math.sqrt(1.04)
+    assert np.allclose(d, unit - 2 * unit[1] * np.array((0.0, 1.0, 0.0)))
+
+
+def test_lambertian_degenerate_direction(oracle):
+    # is_near_zero replaces a vanishing normal + random direction by the normal (main.odin:300-302); cannot be forced
+    # through the RNG, so check the documented threshold on the predicate's inputs via the scatter of a tiny normal
+    material = (0, (0.5, 0.5, 0.5), 0.0)
+    _, d, att, ok = oracle.material_scatter(1, material, (0, 0, 0), (0, -1, 0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 1, 1, 1)
+    assert ok and tuple(att) == (0.5, 0.5, 0.5)
+    assert abs(np.linalg.norm(np.array(d) - np.array((0.0, 1.0, 0.0))) - 1.0) < 1e-12  # normal + unit vector
+
+
+@pytest.mark.parametrize("name", ["two", "dev"])
+def test_f64_render_equals_python_golden(rt, oracle, name):
+    g = np.load(os.path.join(GOLDEN, f"render_{name}_f64.npz"))
+    cs, sph, mat = (rt.build_two_sphere_scene if name == "two" else rt.build_dev_scene)(int(g["width"]))
+    cs.samples_per_pixel = int(g["spp"])
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = int(g["width"]), int(g["height"])
+    r = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=int(g["seed"]))
+    assert np.array_equal(r["image"], g["image"])
+    assert np.array_equal(r["linear"], g["linear"])
+    assert int(r["stats"][0]) == int(g["segments"])
+
+
+@pytest.mark.parametrize("name", ["two", "dev"])
+def test_f32_renders_are_pinned_and_close_to_f64(rt, oracle, name):
+    g32 = np.load(os.path.join(GOLDEN, f"render_{name}_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"render_{name}_f64.npz"))
+    cs, sph, mat = (rt.build_two_sphere_scene if name == "two" else rt.build_dev_scene)(int(g64["width"]))
+    cs.samples_per_pixel = int(g64["spp"])
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = int(g64["width"]), int(g64["height"])
+    for label, precision in (("fma", 0), ("literal", 2)):
+        r = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=int(g64["seed"]))
+        assert np.array_equal(r["image"], g32[f"image_{label}"])
+        # f32 and f64 trace the same paths except where a rounding flips a hit decision (then
+        # that sample's whole path differs): nearly all pixels agree to f32 rounding
+        diff = np.abs(r["linear"] - g64["linear"]).max(axis=2)
+        assert np.mean(diff < 2e-5) > 0.97 and np.median(diff) < 1e-6
+
+
+def test_live_pyref_cross_check_with_region_and_dof(rt, oracle):
+    # a fresh (not pre-generated) comparison on a ragged region of the three-material scene
+    cs, sph, mat = rt.build_dev_scene(24)
+    cs.samples_per_pixel = 3
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    region = (5, 2, 19, 11)
+    spl, ml = as_lists(sph, mat)
+    got, seg = pyref.render_region(w, h, region, cam_dict(cam), spl, ml, 77)
+    r = oracle.render_region(w, h, region, cam, sph, mat, precision=1, seed=77)
+    for (u, v), c in got.items():
+        assert tuple(r["image"][v, u]) == c
+    assert int(r["stats"][0]) == seg
+    outside = np.ones((h, w), dtype=bool)
+    outside[region[1]:region[3], region[0]:region[2]] = False
+    assert np.all(r["image"][outside] == 0.0)
+
+
+def test_empty_world_is_the_sky_gradient(rt, oracle):
+    # no spheres: every sample is lerp(white, (0.5,0.7,1), 0.5*(dir.y+1)); the mean is bounded by the gradient's ends
+    cs, sph, mat = rt.build_two_sphere_scene(32)
+    cs.samples_per_pixel = 8
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    r = oracle.render_region(w, h, (0, 0, w, h), cam, sph[:0], mat[:0], precision=1, seed=5)
+    lin = r["linear"]
+    assert np.all(lin[..., 2] == 1.0)                      # blue is 1 at both ends of the lerp
+    assert np.all((lin[..., 0] >= 0.5) & (lin[..., 0] <= 1.0))
+    assert np.all(np.diff(lin[:, w // 2, 0]) > 0)          # looking down (larger v) the sky whitens: t falls with dir.y
+    assert int(r["stats"][0]) == w * h * 8                 # one segment per sample
+
+
+def test_white_furnace(rt, oracle):
+    # camera inside a huge albedo-1 lambertian sphere: no path escapes, every path runs the full
+    # max_ray_bounces + 1 segments and keeps colour (1,1,1): the bounce-limit rule of main.odin:535
+    sph = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    sph[0] = ((0, 0, 0), 50.0, 0)
+    mat = np.zeros(1, dtype=rt.MATERIAL_DTYPE)
+    mat[0] = (0, (1.0, 1.0, 1.0), 0.0)
+    cs, _, _ = rt.build_two_sphere_scene(16)
+    cs.samples_per_pixel = 2
+    cs.max_ray_bounces = 7
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    for precision in (0, 1, 2):
+        r = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=1)
+        assert np.all(r["image"] == 1.0)
+        assert int(r["stats"][0]) == w * h * 2 * 8
+
+
+def test_sample_split_and_chunks_in_the_oracle(rt, oracle):
+    cs, sph, mat = rt.build_dev_scene(24)
+    cs.samples_per_pixel = 6
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    full = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=9)
+    a = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=9, sample_begin=0, sample_count=2)
+    b = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=9, sample_begin=2, sample_count=4)
+    assert np.array_equal(a["accum"] + b["accum"], full["accum"])  # Q32.32 sums are exact
+    c3 = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=9, sample_chunks=3)
+    assert np.array_equal(c3["image"], full["image"])
+    # multithreaded rows give the same image
+    mt = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=9, threads=4)
+    st = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=9, threads=1)
+    assert np.array_equal(mt["image"], st["image"])
