@@ -52,12 +52,10 @@ def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
     import oracle_lib
     o = oracle_lib.Oracle()
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    probe = (0, height // 2, width, height // 2 + 8)  # 8 rows through the middle of the frame
     t0 = time.perf_counter()
-    o.render_region(width, height, probe, cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-4)
-    est_full_1spp = dt * height / 8.0
-    spp = max(1, min(64, int(seconds / max(est_full_1spp, 1e-3))))
+    o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=cores)
+    est_full_1spp = max(time.perf_counter() - t0, 1e-4)  # the whole frame at 1 spp
+    spp = max(1, min(512, int(seconds / est_full_1spp)))
     t0 = time.perf_counter()
     r = o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=spp, threads=cores)
     dt = time.perf_counter() - t0

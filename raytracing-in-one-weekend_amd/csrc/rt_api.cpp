@@ -206,9 +206,9 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     HIP_TRY(hipGetDevice(&current));
 
     const size_t ns = static_cast<size_t>(n_spheres), nm = static_cast<size_t>(n_materials);
-    // records are padded to a multiple of GROUP, plus one group the scan may prefetch; a pad
+    // records are padded to a multiple of SCAN_STEP, plus one group the scan may prefetch; a pad
     // record has r*r = -inf, which makes its discriminant -inf (or NaN): never a candidate
-    const size_t ns_pad = (ns + rtk::GROUP - 1) / rtk::GROUP * rtk::GROUP;
+    const size_t ns_pad = (ns + rtk::SCAN_STEP - 1) / rtk::SCAN_STEP * rtk::SCAN_STEP;
     const size_t ns_alloc = ns_pad + rtk::GROUP;
     std::vector<float> rec32(4 * ns_alloc, 0.0f), rad32(ns), mat32(4 * nm);
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);

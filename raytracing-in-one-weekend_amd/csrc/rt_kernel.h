@@ -9,6 +9,7 @@ constexpr int TILE = 8;              // a wave64 owns one 8x8-pixel tile, lane l
 constexpr int WAVES_PER_BLOCK = 4;   // 256-thread workgroups: four tiles share one LDS copy of the spheres
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 constexpr int GROUP = 4;             // sphere records are fetched and tested four at a time
+constexpr int SCAN_STEP = 2 * GROUP;  // spheres per iteration of the scan loop (two register sets)
 constexpr int REJECTION_CAP = 64;    // bound on the two rejection-sampling loops (P(reaching it) < 1e-20)
 constexpr int LDS_MAX_SPHERES_F32 = 4088; // just under 64 KiB of float4 records per workgroup
 constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 records per workgroup
@@ -43,7 +44,7 @@ struct RenderParams {
     const int32_t *sphere_material;
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
     const int32_t *material_type;
-    int32_t n_spheres;          // padded to a multiple of GROUP (pad records have r*r = -inf); GROUP more follow
+    int32_t n_spheres;          // padded to a multiple of SCAN_STEP (pad records have r*r = -inf); GROUP more follow
     // image and work
     int32_t width, height;
     int32_t min_x, min_y, max_x, max_y; // region, half open

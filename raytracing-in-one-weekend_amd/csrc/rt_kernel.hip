@@ -154,7 +154,7 @@ template <typename Real, bool FMA, int FETCH, bool QUEUE>
 __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
-    const int n = P.n_spheres; // padded count, a multiple of GROUP
+    const int n = P.n_spheres; // padded count, a multiple of SCAN_STEP
 
     // The records never change during a launch.  Reading them through the constant address
     // space tells the compiler so: a wave-uniform index then becomes a scalar-cache load into
@@ -325,25 +325,29 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (cand) { pend_h = h; pend_disc = disc; pend = i; }
             }
         };
-        // The record array is padded to a multiple of GROUP with records that can never be hit
+        // The record array is padded to a multiple of SCAN_STEP with records that can never be hit
         // (r*r = -inf) plus one more group, so the next group is always loadable while the
         // current one is tested.  One compare covers a group: the largest of the four
         // discriminants (NaNs ignored) is negative in every lane for most groups.
-        auto test_group = [&](const R4 &s0, const R4 &s1, const R4 &s2, const R4 &s3, const int i) {
-            Real h0, h1, h2, h3, k0, k1, k2, k3;
-            const Real d0 = discriminant(s0, h0, k0), d1 = discriminant(s1, h1, k1);
-            const Real d2 = discriminant(s2, h2, k2), d3 = discriminant(s3, h3, k3);
-            const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {
-                park(h0, k0, d0, i); park(h1, k1, d1, i + 1); park(h2, k2, d2, i + 2); park(h3, k3, d3, i + 3);
-            }
-        };
-        R4 c0 = rec(0), c1 = rec(1), c2 = rec(2), c3 = rec(3);
-        for (int i = 0; i < n; i += GROUP) {
-            const R4 p0 = rec(i + 4), p1 = rec(i + 5), p2 = rec(i + 6), p3 = rec(i + 7);
-            test_group(c0, c1, c2, c3, i);
-            c0 = p0; c1 = p1; c2 = p2; c3 = p3;
+#define RT_TEST_GROUP(s0, s1, s2, s3, i)                                                                  \
+    do {                                                                                                  \
+        Real h0, h1, h2, h3, k0, k1, k2, k3;                                                              \
+        const Real d0 = discriminant(s0, h0, k0), d1 = discriminant(s1, h1, k1);                          \
+        const Real d2 = discriminant(s2, h2, k2), d3 = discriminant(s3, h3, k3);                          \
+        const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));                                      \
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {                  \
+            park(h0, k0, d0, (i)); park(h1, k1, d1, (i) + 1); park(h2, k2, d2, (i) + 2); park(h3, k3, d3, (i) + 3); \
+        }                                                                                                 \
+    } while (0)
+        // two register sets, A and B, each holding one group: while one is tested the other loads
+        R4 a0 = rec(0), a1 = rec(1), a2 = rec(2), a3 = rec(3);
+        for (int i = 0; i < n; i += 2 * GROUP) {
+            const R4 b0 = rec(i + 4), b1 = rec(i + 5), b2 = rec(i + 6), b3 = rec(i + 7);
+            RT_TEST_GROUP(a0, a1, a2, a3, i);
+            a0 = rec(i + 8); a1 = rec(i + 9); a2 = rec(i + 10); a3 = rec(i + 11);
+            RT_TEST_GROUP(b0, b1, b2, b3, i + 4);
         }
+#undef RT_TEST_GROUP
         if (pend >= 0) resolve();
         ++segments;
 
