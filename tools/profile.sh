@@ -15,6 +15,7 @@ pass() {
 }
 pass pmc1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
 pass pmc2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32
+pass pmc4 FETCH_SIZE
+pass pmc5 WRITE_SIZE
 pass pmc3 SQ_LEVEL_WAVES SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_SMEM GRBM_GUI_ACTIVE
-find "$OUT" -name "*.csv" | head -30
-python3 tools/summarize_prof.py "$OUT"
+python3 tools/summarize_prof.py "$OUT" | tee "$OUT/summary.txt"

@@ -1,0 +1,78 @@
+// Command-line host for the GPU renderer: what `main` of the reference does (main.odin:826-852)
+// through the C ABI -- build a scene, compute the camera, render, print a P3 PPM to stdout --
+// with the scene, size, sample count and seed selectable at run time.
+//   rt_cli [--scene dev|two|final|stress] [--width W] [--spp N] [--depth D] [--seed S]
+//          [--gpus G] [--precision f32|f64|f32-literal] [--stochastic] [--stats] > out.ppm
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/rt_mi355x.h"
+
+int main(int argc, char **argv) {
+    std::string scene = "dev", precision = "f32";
+    int64_t width = 0, spp = 0, depth = -1;
+    uint64_t seed = 1;
+    int gpus = 1;
+    bool stochastic = false, want_stats = false;
+    for (int i = 1; i < argc; ++i) {
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", argv[i]); std::exit(2); } return argv[++i]; };
+        if (!std::strcmp(argv[i], "--scene")) scene = next();
+        else if (!std::strcmp(argv[i], "--width")) width = std::atoll(next());
+        else if (!std::strcmp(argv[i], "--spp")) spp = std::atoll(next());
+        else if (!std::strcmp(argv[i], "--depth")) depth = std::atoll(next());
+        else if (!std::strcmp(argv[i], "--seed")) seed = std::strtoull(next(), nullptr, 0);
+        else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--precision")) precision = next();
+        else if (!std::strcmp(argv[i], "--stochastic")) stochastic = true;
+        else if (!std::strcmp(argv[i], "--stats")) want_stats = true;
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    rt_camera_settings settings;
+    std::vector<rt_sphere> spheres(16384);
+    std::vector<rt_material> materials(16384);
+    int64_t ns = static_cast<int64_t>(spheres.size()), nm = static_cast<int64_t>(materials.size());
+    int32_t rc;
+    if (scene == "dev") rc = rt_build_dev_scene(width, &settings, spheres.data(), &ns, materials.data(), &nm);
+    else if (scene == "two") rc = rt_build_two_sphere_scene(width, &settings, spheres.data(), &ns, materials.data(), &nm);
+    else if (scene == "final") rc = rt_build_final_scene(seed, width, &settings, spheres.data(), &ns, materials.data(), &nm);
+    else if (scene == "stress") rc = rt_build_stress_scene(5, 10000, width, &settings, spheres.data(), &ns, materials.data(), &nm);
+    else { std::fprintf(stderr, "unknown scene %s\n", scene.c_str()); return 2; }
+    if (rc != RT_OK) { std::fprintf(stderr, "scene builder failed: %d\n", rc); return 1; }
+    if (spp > 0) settings.samples_per_pixel = spp;
+    if (depth >= 0) settings.max_ray_bounces = depth;
+
+    const int64_t w = static_cast<int64_t>(settings.image_size_x), h = static_cast<int64_t>(settings.image_size_y);
+    std::vector<rt_v3> image(static_cast<size_t>(w * h));
+    rt_camera_render_data cam;
+    rt_calculate_camera_render_data(&settings, &cam);
+
+    rt_options opts;
+    rt_options_default(&opts);
+    opts.seed = seed;
+    opts.rng_mode = stochastic ? RT_RNG_STOCHASTIC : RT_RNG_DETERMINISTIC;
+    opts.precision = precision == "f64" ? RT_PRECISION_F64 : precision == "f32-literal" ? RT_PRECISION_F32_LITERAL : RT_PRECISION_F32;
+    opts.device_count = gpus;
+    uint64_t stats[RT_STATS_COUNT] = {0};
+    opts.stats = stats;
+    std::fprintf(stderr, "%s: %s scene, %lld spheres, %lldx%lld, %lld spp, depth %lld, %d GPU(s)\n", rt_version(), scene.c_str(), (long long)ns,
+                 (long long)w, (long long)h, (long long)settings.samples_per_pixel, (long long)settings.max_ray_bounces, gpus);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = rt_render_tiled(image.data(), w, h, &cam, spheres.data(), ns, materials.data(), nm, &opts);
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != RT_OK) { std::fprintf(stderr, "rt_render_tiled failed (%d): %s\n", rc, rt_last_error()); return 1; }
+    if (want_stats)
+        std::fprintf(stderr, "Done. %.3f s wall (%.1f Msamples/s incl. copies), kernel %.3f ms, %.3f segments/sample, %llu sphere tests\n", seconds,
+                     w * h * settings.samples_per_pixel / seconds / 1e6, stats[RT_STAT_KERNEL_NS] / 1e6,
+                     double(stats[RT_STAT_SEGMENTS]) / double(stats[RT_STAT_SAMPLES]), (unsigned long long)stats[RT_STAT_SPHERE_TESTS]);
+    else
+        std::fprintf(stderr, "Done.\n");
+    const int64_t need = rt_serialize_ppm(image.data(), w, h, nullptr, 0);
+    std::vector<char> ppm(static_cast<size_t>(need));
+    rt_serialize_ppm(image.data(), w, h, ppm.data(), need);
+    std::fwrite(ppm.data(), 1, ppm.size(), stdout);
+    return 0;
+}
