@@ -19,8 +19,9 @@
  * Real = double, FMA = false : the reference's arithmetic as written (v3 :: [3]f64,
  *                              main.odin:19; LLVM does not contract a*b+c without fast-math).
  * Real = float,  FMA = false : the same operation order in f32.
- * Real = float,  FMA = true  : as above, but the three dot-product chains of the
- *                              ray/sphere test use fused multiply-adds, and sample colours
+ * Real = float,  FMA = true  : as above, but the ray/sphere test is evaluated in its expanded
+ *                              form with fused multiply-adds (ray_sphere_intersection_expanded
+ *                              below), and sample colours
  *                              are summed exactly in Q32.32 with an f64 mean and square
  *                              root -- the arithmetic of the GPU throughput kernel.
  */
@@ -170,27 +171,15 @@ template <class Real> inline vec3<Real> random_point_on_disk(draw_stream &g) {
 template <class Real> struct ray_t { vec3<Real> origin, direction; };
 template <class Real> struct hit_record { vec3<Real> p, normal; bool front_face; };
 
-inline float fused(float a, float b, float c) { return std::fmaf(a, b, c); }
-inline double fused(double a, double b, double c) { return std::fma(a, b, c); }
-
 /* ray_sphere_intersection  main.odin:240-263.  returns t in [t_min, t_max) or t_max. */
-template <class Real, bool FMA>
+template <class Real>
 inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real radius, Real t_min, Real t_max) {
     Real t = t_max;
     vec3<Real> oc = c - r.origin;
-    Real a, h, cc, disc;
-    if (FMA) {
-        const vec3<Real> d = r.direction;
-        a = magnitude_squared(d);
-        h = fused(d.z, oc.z, fused(d.y, oc.y, d.x * oc.x));
-        cc = fused(oc.z, oc.z, fused(oc.y, oc.y, fused(oc.x, oc.x, -(radius * radius))));
-        disc = fused(h, h, -(a * cc));
-    } else {
-        a = magnitude_squared(r.direction);
-        h = dot(r.direction, oc);
-        cc = magnitude_squared(oc) - radius * radius;
-        disc = h * h - a * cc;
-    }
+    Real a = magnitude_squared(r.direction);
+    Real h = dot(r.direction, oc);
+    Real cc = magnitude_squared(oc) - radius * radius;
+    Real disc = h * h - a * cc;
     if (disc < 0) return t;
     Real sqrtd = std::sqrt(disc);
     Real root = (h - sqrtd) / a;
@@ -200,6 +189,45 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
     }
     t = root;
     return t;
+}
+
+/* The ray/sphere test of the GPU throughput arithmetic (f32).  Same algebra as
+ * main.odin:245-249 with the squares expanded so that both h and c are dot products of a
+ * per-sphere vector with a per-ray vector:
+ *     h = d.(center - o)         = d.center - d.o
+ *     c = |center - o|^2 - r^2   = (|center|^2 - r^2) - 2 center.o + |o|^2
+ * Per sphere: K = |center|^2 - r^2 (formed in f64 from the f32 centre and radius, rounded to
+ * f32).  Per segment: d_o = d.o, o_o = o.o, a = d.d (plain left-to-right dot products) and
+ * -2*o (exact).  Then, with fused multiply-adds in exactly this order,
+ *     h    = fma(cz, dz, fma(cy, dy, fma(cx, dx, -d_o)))
+ *     c    = fma(K, 1, fma(cz, -2oz, fma(cy, -2oy, fma(cx, -2ox, o_o))))      (the last step is + K)
+ *     disc = fma(h, h, -(a*c))
+ * and the roots, range tests and tie rule of main.odin:250-261 unchanged. */
+struct expanded_ray { float dx, dy, dz, d_o, m2ox, m2oy, m2oz, o_o, a; };
+inline expanded_ray expand_ray(const ray_t<float> &r) {
+    expanded_ray e;
+    e.dx = r.direction.x; e.dy = r.direction.y; e.dz = r.direction.z;
+    e.d_o = dot(r.direction, r.origin);
+    e.o_o = dot(r.origin, r.origin);
+    e.a = dot(r.direction, r.direction);
+    e.m2ox = -2.0f * r.origin.x; e.m2oy = -2.0f * r.origin.y; e.m2oz = -2.0f * r.origin.z;
+    return e;
+}
+inline float sphere_constant(float cx, float cy, float cz, float radius) {
+    return static_cast<float>(static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz - static_cast<double>(radius) * radius);
+}
+inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float> c, float K, float t_min, float t_max) {
+    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
+    const float cc = std::fmaf(c.z, e.m2oz, std::fmaf(c.y, e.m2oy, std::fmaf(c.x, e.m2ox, e.o_o))) + K;
+    const float disc = std::fmaf(h, h, -(e.a * cc));
+    if (disc < 0) return t_max;
+    const float sqrtd = std::sqrt(disc);
+    float root = (h - sqrtd) / e.a;
+    if (root < t_min || t_max <= root) {
+        root = (h + sqrtd) / e.a;
+        if (root < t_min || t_max <= root) return t_max;
+    }
+    return root;
 }
 
 /* ---------------------------------------------------------------- materials  main.odin:268-410 */
@@ -262,7 +290,7 @@ template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
 }
 
 /* ---------------------------------------------------------------- the world in Real */
-template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; };
+template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K; /* |center|^2 - r^2, throughput arithmetic only */ };
 template <class Real> struct camera_t {
     vec3<Real> position, du, dv, top_left, dof_u, dof_v;
     Real dof_angle;
@@ -276,7 +304,9 @@ template <class Real> struct scene_t {
     int64_t max_ray_bounces;
     scene_t(const rt_camera_render_data *c, const rt_sphere *s, int64_t ns, const rt_material *m, int64_t nm) {
         spheres.resize(ns);
-        for (int64_t i = 0; i < ns; ++i) spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index};
+        for (int64_t i = 0; i < ns; ++i)
+            spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index,
+                          sphere_constant(static_cast<float>(s[i].center.x), static_cast<float>(s[i].center.y), static_cast<float>(s[i].center.z), static_cast<float>(s[i].radius))};
         materials.resize(nm);
         for (int64_t i = 0; i < nm; ++i) materials[i] = {m[i].type, cvt<Real>(m[i].albedo), static_cast<Real>(m[i].param1)};
         cam = {cvt<Real>(c->position), cvt<Real>(c->pixel_delta_u), cvt<Real>(c->pixel_delta_v),
@@ -310,9 +340,17 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
         Real closest_t = std::numeric_limits<Real>::max();
         int64_t hit_index = -1;
         const Real SHADOW_ACNE_RAY_OFFSET = Real(0.001);
-        for (int64_t i = 0; i < n; ++i) {
-            Real t = ray_sphere_intersection<Real, FMA>(ray, sc.spheres[i].center, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
-            if (t < closest_t) { closest_t = t; hit_index = i; }
+        if constexpr (FMA) {
+            const expanded_ray e = expand_ray(ray);
+            for (int64_t i = 0; i < n; ++i) {
+                Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                if (t < closest_t) { closest_t = t; hit_index = i; }
+            }
+        } else {
+            for (int64_t i = 0; i < n; ++i) {
+                Real t = ray_sphere_intersection<Real>(ray, sc.spheres[i].center, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                if (t < closest_t) { closest_t = t; hit_index = i; }
+            }
         }
         if (hit_index >= 0) {
             const sphere_t<Real> &sp = sc.spheres[hit_index];
@@ -479,12 +517,13 @@ double oracle_ray_sphere_intersection(int32_t precision, const double *o, const 
                                       double radius, double t_min, double t_max) {
     if (precision == RT_PRECISION_F64) {
         ray_t<double> r{{o[0], o[1], o[2]}, {d[0], d[1], d[2]}};
-        return ray_sphere_intersection<double, false>(r, {c[0], c[1], c[2]}, radius, t_min, t_max);
+        return ray_sphere_intersection<double>(r, {c[0], c[1], c[2]}, radius, t_min, t_max);
     }
     ray_t<float> r{{(float)o[0], (float)o[1], (float)o[2]}, {(float)d[0], (float)d[1], (float)d[2]}};
     vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
-    if (precision == RT_PRECISION_F32) return ray_sphere_intersection<float, true>(r, cf, (float)radius, (float)t_min, (float)t_max);
-    return ray_sphere_intersection<float, false>(r, cf, (float)radius, (float)t_min, (float)t_max);
+    if (precision == RT_PRECISION_F32)
+        return ray_sphere_intersection_expanded(expand_ray(r), cf, sphere_constant(cf.x, cf.y, cf.z, (float)radius), (float)t_min, (float)t_max);
+    return ray_sphere_intersection<float>(r, cf, (float)radius, (float)t_min, (float)t_max);
 }
 
 /* material_scatter for one hit; the draws are those of (seed, pixel, sample, bounce).

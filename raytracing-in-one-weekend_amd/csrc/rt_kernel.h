@@ -39,7 +39,9 @@ struct TileMap {
 
 struct RenderParams {
     // world, structure of arrays (device pointers)
-    const void *sphere_rec;     // per sphere {cx, cy, cz, r*r} in float4 / double4
+    const void *sphere_rec;     // scan records: float4 / double4 {cx, cy, cz, r*r}; throughput mode: per PAIR of spheres
+                                // {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} with K = |c|^2 - r*r
+    const void *sphere_center;  // float4 / double4 {cx, cy, cz, r*r}: the centre is read from here on a hit
     const void *sphere_radius;  // per sphere radius, float / double
     const int32_t *sphere_material;
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4

@@ -15,9 +15,11 @@
 // Closest-hit scan
 //   The sphere index is wave-uniform: records {cx, cy, cz, r*r} come four at a time through the
 //   scalar cache into SGPRs (or from LDS), the next four being fetched while these are tested.
-//   Per sphere a lane spends 3 subtractions, 3+3 fused multiply-adds for h = d.oc and
-//   |oc|^2 - r^2, and a multiply + fma for the discriminant (main.odin:245-249 with a = |d|^2
-//   and r^2 hoisted), then one compare.  Only when some lane's line meets the sphere does the
+//   Per sphere a lane spends 3+3 fused multiply-adds for h = d.c - d.o and
+//   c = (|c|^2 - r^2) - 2 c.o + |o|^2, an add, and a multiply + fma for the discriminant
+//   (main.odin:245-249 with the squares expanded and the per-ray and per-sphere parts
+//   hoisted), all as packed instructions on two spheres at once; a group of four spheres
+//   shares one compare.  Only when some lane's line meets the sphere does the
 //   wave leave the straight-line code; such a lane parks the candidate (h, disc, index) in
 //   registers and the square root / divisions / range tests of main.odin:252-261 run later, for
 //   all parked lanes at once, when a lane needs its slot again or the scan ends.  A lane's
@@ -139,6 +141,10 @@ __device__ __forceinline__ unsigned long long to_q32_32(float x) {
 }
 __device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; } // never used: QUEUE is f32 only
 
+typedef float F2 __attribute__((ext_vector_type(2)));
+struct Pair { F2 cx, cy, cz, k; }; // two spheres' scan records, component-wise
+__device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); } // v_pk_fma_f32
+
 // number of lanes below this one whose bit is set in `mask`
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -168,6 +174,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
         for (int i = threadIdx.x; i < n + GROUP; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
         __syncthreads();
     }
+    // throughput mode: pair j = spheres 2j and 2j+1 as {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
+    auto pair = [&](int j) -> Pair {
+        Pair p;
+        if constexpr (FETCH == FETCH_LDS) {
+            const float *l = reinterpret_cast<const float *>(lds_raw) + 8 * j;
+            p.cx = F2{l[0], l[1]}; p.cy = F2{l[2], l[3]}; p.cz = F2{l[4], l[5]}; p.k = F2{l[6], l[7]};
+        } else {
+            typedef const float __attribute__((address_space(4))) *ConstF;
+            ConstF c = (ConstF)(P.sphere_rec) + 8 * j;
+            p.cx = F2{c[0], c[1]}; p.cy = F2{c[2], c[3]}; p.cz = F2{c[4], c[5]}; p.k = F2{c[6], c[7]};
+        }
+        return p;
+    };
     auto rec = [&](int i) -> R4 {
         if constexpr (FETCH == FETCH_LDS) return l_rec[i];
         else { R4 r; r.x = c_rec[4 * i]; r.y = c_rec[4 * i + 1]; r.z = c_rec[4 * i + 2]; r.w = c_rec[4 * i + 3]; return r; }
@@ -206,6 +225,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
     int bounce = 0;
     bool fresh = true;
     uint32_t segments = 0, started = 0;
+#ifdef RT_DIAG_COUNTERS
+    // diagnostic build: how often the scan leaves its straight-line code
+    uint32_t diag_entries = 0, diag_resolves = 0, diag_parked = 0;
+#define RT_DIAG_COUNT(x) (++(x))
+#else
+#define RT_DIAG_COUNT(x) ((void)0)
+#endif
 
     for (;;) {
         if constexpr (QUEUE) {
@@ -289,6 +315,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
         int pend = -1;
 
         auto resolve = [&]() {
+            RT_DIAG_COUNT(diag_resolves);
             // main.odin:252-261 for the parked candidate, then :542-545
             Real sq = sqrt_rn(pend_disc);
             Real root = (pend_h - sq) / a;
@@ -300,19 +327,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             if (!rejected && root < closest) { closest = root; hit = pend; }
             pend = -1;
         };
-        // discriminant of main.odin:245-249 for one sphere; also yields h and c
-        auto discriminant = [&](const R4 sp, Real &h, Real &cc) -> Real {
-            const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
-            if (FMA) {
-                h = fma_rn(rd.z, ocz, fma_rn(rd.y, ocy, rd.x * ocx));
-                cc = fma_rn(ocz, ocz, fma_rn(ocy, ocy, fma_rn(ocx, ocx, -sp.w)));
-                return fma_rn(h, h, -(a * cc));
-            } else {
-                h = rd.x * ocx + rd.y * ocy + rd.z * ocz;
-                cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
-                return h * h - a * cc;
-            }
-        };
         // the uncommon continuation for one sphere: some lane's line meets it
         auto park = [&](const Real h, const Real cc, const Real disc, const int i) {
             if (__builtin_amdgcn_ballot_w64(disc >= Real(0)) != 0ull) {
@@ -322,39 +336,85 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
                 }
-                if (cand) { pend_h = h; pend_disc = disc; pend = i; }
+                if (cand) { pend_h = h; pend_disc = disc; pend = i; RT_DIAG_COUNT(diag_parked); }
             }
         };
-        // The record array is padded to a multiple of SCAN_STEP with records that can never be hit
-        // (r*r = -inf) plus one more group, so the next group is always loadable while the
-        // current one is tested.  One compare covers a group: the largest of the four
+        // The record array is padded to a multiple of SCAN_STEP with records that can never be
+        // hit, plus one more group, so the next group is always loadable while the current one
+        // is tested.  One compare covers a group of four spheres: the largest of the four
         // discriminants (NaNs ignored) is negative in every lane for most groups.
-#define RT_TEST_GROUP(s0, s1, s2, s3, i)                                                                  \
-    do {                                                                                                  \
-        Real h0, h1, h2, h3, k0, k1, k2, k3;                                                              \
-        const Real d0 = discriminant(s0, h0, k0), d1 = discriminant(s1, h1, k1);                          \
-        const Real d2 = discriminant(s2, h2, k2), d3 = discriminant(s3, h3, k3);                          \
-        const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));                                      \
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {                  \
-            park(h0, k0, d0, (i)); park(h1, k1, d1, (i) + 1); park(h2, k2, d2, (i) + 2); park(h3, k3, d3, (i) + 3); \
-        }                                                                                                 \
-    } while (0)
-        // two register sets, A and B, each holding one group: while one is tested the other loads
-        R4 a0 = rec(0), a1 = rec(1), a2 = rec(2), a3 = rec(3);
-        for (int i = 0; i < n; i += 2 * GROUP) {
-            const R4 b0 = rec(i + 4), b1 = rec(i + 5), b2 = rec(i + 6), b3 = rec(i + 7);
-            RT_TEST_GROUP(a0, a1, a2, a3, i);
-            a0 = rec(i + 8); a1 = rec(i + 9); a2 = rec(i + 10); a3 = rec(i + 11);
-            RT_TEST_GROUP(b0, b1, b2, b3, i + 4);
+        if constexpr (FMA) {
+            // Throughput arithmetic.  The squares of main.odin:245-249 are expanded so that h and
+            // c are dot products of a per-sphere record {centre, K = |centre|^2 - r^2} with
+            // per-ray vectors:   h = d.centre - d.o      c = K - 2 centre.o + |o|^2,
+            // each a chain of three fused multiply-adds (plus one add for K).  Records are stored
+            // as PAIRS of spheres {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} and every operation is a
+            // packed one (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32) on two spheres at once: a
+            // plain VALU instruction with an SGPR source issues at half rate on gfx950, a packed
+            // one with an SGPR-pair source at full rate.  Pad records have K = FLT_MAX: c and a*c
+            // overflow and the discriminant is -inf.
+            const float d_o = dot(rd, ro), o_o = dot(ro, ro);
+            const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
+            const F2 ox2 = {-2.0f * ro.x, -2.0f * ro.x}, oy2 = {-2.0f * ro.y, -2.0f * ro.y}, oz2 = {-2.0f * ro.z, -2.0f * ro.z};
+            const F2 oo2 = {o_o, o_o}, a2 = {a, a};
+            auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
+                const F2 hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
+                const F2 hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
+                const F2 cp = fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))) + p.k;
+                const F2 cq = fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))) + q.k;
+                const F2 dp = fma2(hp, hp, -(a2 * cp));
+                const F2 dq = fma2(hq, hq, -(a2 * cq));
+                const float dmax = max_num(max_num(dp.x, dp.y), max_num(dq.x, dq.y));
+#ifdef RT_DIAG_NO_PARK
+                asm volatile("" :: "v"(dmax));
+                if (false) {
+#else
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= 0.0f) != 0ull, 0)) {
+#endif
+                    RT_DIAG_COUNT(diag_entries);
+                    park(hp.x, cp.x, dp.x, i); park(hp.y, cp.y, dp.y, i + 1); park(hq.x, cq.x, dq.x, i + 2); park(hq.y, cq.y, dq.y, i + 3);
+                }
+            };
+            // two register sets, A and B, each holding one group: while one is tested the other loads
+            Pair a0 = pair(0), a1 = pair(1);
+            for (int i = 0; i < n; i += 2 * GROUP) {
+                const Pair b0 = pair(i / 2 + 2), b1 = pair(i / 2 + 3);
+                test_pairs(a0, a1, i);
+                a0 = pair(i / 2 + 4); a1 = pair(i / 2 + 5);
+                test_pairs(b0, b1, i + 4);
+            }
+        } else {
+            // literal modes: records are {centre, r*r}, the reference's expressions (main.odin:245-249)
+            auto discriminant = [&](const R4 sp, Real &h, Real &cc) -> Real {
+                const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
+                h = rd.x * ocx + rd.y * ocy + rd.z * ocz;
+                cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                return h * h - a * cc;
+            };
+            auto test_group = [&](const R4 &s0, const R4 &s1, const R4 &s2, const R4 &s3, const int i) {
+                Real h0, h1, h2, h3, k0, k1, k2, k3;
+                const Real d0 = discriminant(s0, h0, k0), d1 = discriminant(s1, h1, k1);
+                const Real d2 = discriminant(s2, h2, k2), d3 = discriminant(s3, h3, k3);
+                const Real dmax = max_num(max_num(d0, d1), max_num(d2, d3));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= Real(0)) != 0ull, 0)) {
+                    park(h0, k0, d0, i); park(h1, k1, d1, i + 1); park(h2, k2, d2, i + 2); park(h3, k3, d3, i + 3);
+                }
+            };
+            R4 a0 = rec(0), a1 = rec(1), a2 = rec(2), a3 = rec(3);
+            for (int i = 0; i < n; i += 2 * GROUP) {
+                const R4 b0 = rec(i + 4), b1 = rec(i + 5), b2 = rec(i + 6), b3 = rec(i + 7);
+                test_group(a0, a1, a2, a3, i);
+                a0 = rec(i + 8); a1 = rec(i + 9); a2 = rec(i + 10); a3 = rec(i + 11);
+                test_group(b0, b1, b2, b3, i + 4);
+            }
         }
-#undef RT_TEST_GROUP
         if (pend >= 0) resolve();
         ++segments;
 
         // ---------------- shading
         bool ended;
         if (hit >= 0) {
-            const R4 sp = g_rec[hit];
+            const R4 sp = static_cast<const R4 *>(P.sphere_center)[hit];
             const Real radius = static_cast<const Real *>(P.sphere_radius)[hit];
             const int mi = P.sphere_material[hit];
             const int mtype = P.material_type[mi];
@@ -461,6 +521,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             atomicAdd(&P.stats[3], static_cast<unsigned long long>(smp));
             atomicAdd(&P.stats[4], static_cast<unsigned long long>(iters));
         }
+#ifdef RT_DIAG_COUNTERS
+        // entries: per wave (uniform, take lane 0's); resolves: wave-level calls (max over lanes approximates); parked: lane total
+        uint32_t par = diag_parked, res = diag_resolves;
+        for (int off = 32; off > 0; off >>= 1) { par += __shfl_xor(par, off, 64); res += __shfl_xor(res, off, 64); }
+        if (lane == 0) {
+            atomicAdd(&P.stats[5], static_cast<unsigned long long>(diag_entries));
+            atomicAdd(&P.stats[6], static_cast<unsigned long long>(res));
+            atomicAdd(&P.stats[7], static_cast<unsigned long long>(par));
+        }
+#endif
     }
 }
 

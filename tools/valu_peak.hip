@@ -28,6 +28,52 @@ __global__ void fma_scalar(float *out, float b, float c) {
     if (s == 123.456f) out[0] = s; // never true: keeps the chain alive
 }
 
+// the same stream with one operand of every fma in an SGPR (how the scan reads sphere records)
+__global__ void fma_sgpr(float *out, float b, float c) {
+    float acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = threadIdx.x * 1e-6f + i;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(acc[i]) : "s"(b), "v"(c));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    if (s == 123.456f) out[0] = s;
+}
+
+// VOP2 encoding with an SGPR source: v_fmac_f32 acc, s, v
+__global__ void fmac_sgpr(float *out, float b, float c) {
+    float acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = threadIdx.x * 1e-6f + i;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "s"(b), "v"(c));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    if (s == 123.456f) out[0] = s;
+}
+
+// packed fma with one operand an SGPR pair (two spheres' worth of a record component)
+__global__ void fma_packed_sgpr(float *out, float b, float c) {
+    v2f acc[ACC / 2];
+    const v2f vb = {b, b * 1.0001f}, vc = {c, c * 0.9999f};
+#pragma unroll
+    for (int i = 0; i < ACC / 2; ++i) acc[i] = v2f{threadIdx.x * 1e-6f + i, threadIdx.x * 2e-6f + i};
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC / 2; ++i) asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc[i]) : "s"(vb), "v"(vc));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC / 2; ++i) s += acc[i].x + acc[i].y;
+    if (s == 123.456f) out[0] = s;
+}
+
 __global__ void fma_packed(float *out, float b, float c) {
     v2f acc[ACC / 2];
     const v2f vb = {b, b * 1.0001f}, vc = {c, c * 0.9999f};
@@ -86,10 +132,13 @@ int main() {
         const double flops = 256.0 * waves_per_simd * 256 * double(ITERS) * ACC * 2;
         double ts = run(fma_scalar, waves_per_simd, 256, d);
         double tp = run(fma_packed, waves_per_simd, 256, d);
+        double tsg = run(fma_sgpr, waves_per_simd, 256, d);
+        double tpsg = run(fma_packed_sgpr, waves_per_simd, 256, d);
+        double tsc = run(fmac_sgpr, waves_per_simd, 256, d);
         const double mix_flops = 256.0 * waves_per_simd * 256 * double(ITERS) * 17;
         double tm = run(sphere_mix, waves_per_simd, 256, d);
-        printf("waves/SIMD %d: v_fma_f32 %.1f TFLOP/s   v_pk_fma_f32 %.1f TFLOP/s   sphere-mix %.1f TFLOP/s (17 FLOP/test)\n", waves_per_simd,
-               flops / ts * 1e-12, flops / tp * 1e-12, mix_flops / tm * 1e-12);
+        printf("waves/SIMD %d: v_fma_f32 %.1f TFLOP/s   v_pk_fma_f32 %.1f   v_fma_f32 (SGPR src) %.1f   v_fmac_f32 (SGPR src) %.1f   v_pk_fma_f32 (SGPR pair src) %.1f   sphere-mix %.1f (17 FLOP/test)\n", waves_per_simd,
+               flops / ts * 1e-12, flops / tp * 1e-12, flops / tsg * 1e-12, flops / tsc * 1e-12, flops / tpsg * 1e-12, mix_flops / tm * 1e-12);
         if (flops / ts > best_scalar) best_scalar = flops / ts;
         if (flops / tp > best_packed) best_packed = flops / tp;
         if (mix_flops / tm > best_mix) best_mix = mix_flops / tm;
