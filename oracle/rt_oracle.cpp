@@ -192,25 +192,27 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
 }
 
 /* The ray/sphere test of the GPU throughput arithmetic (f32).  Same algebra as
- * main.odin:245-249 with the squares expanded so that both h and c are dot products of a
+ * main.odin:245-249 with the squares expanded so that both h and a*c are dot products of a
  * per-sphere vector with a per-ray vector:
- *     h = d.(center - o)         = d.center - d.o
- *     c = |center - o|^2 - r^2   = (|center|^2 - r^2) - 2 center.o + |o|^2
+ *     h   = d.(center - o)            = d.center - d.o
+ *     a*c = a(|center - o|^2 - r^2)   = a(|center|^2 - r^2) - 2a center.o + a|o|^2
  * Per sphere: K = |center|^2 - r^2 (formed in f64 from the f32 centre and radius, rounded to
- * f32).  Per segment: d_o = d.o, o_o = o.o, a = d.d (plain left-to-right dot products) and
- * -2*o (exact).  Then, with fused multiply-adds in exactly this order,
+ * f32).  Per segment: a = d.d, d_o = d.o, o_o = o.o (plain left-to-right dot products), then
+ * aox = a*(-2*ox) (likewise y, z) and aoo = a*o_o, each one rounded product.  Then, with fused
+ * multiply-adds in exactly this order,
  *     h    = fma(cz, dz, fma(cy, dy, fma(cx, dx, -d_o)))
- *     c    = fma(K, 1, fma(cz, -2oz, fma(cy, -2oy, fma(cx, -2ox, o_o))))      (the last step is + K)
- *     disc = fma(h, h, -(a*c))
+ *     m    = fma(K, a, fma(cz, aoz, fma(cy, aoy, fma(cx, aox, aoo))))        ( = a*c )
+ *     disc = fma(h, h, -m)
  * and the roots, range tests and tie rule of main.odin:250-261 unchanged. */
-struct expanded_ray { float dx, dy, dz, d_o, m2ox, m2oy, m2oz, o_o, a; };
+struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a; };
 inline expanded_ray expand_ray(const ray_t<float> &r) {
     expanded_ray e;
     e.dx = r.direction.x; e.dy = r.direction.y; e.dz = r.direction.z;
     e.d_o = dot(r.direction, r.origin);
-    e.o_o = dot(r.origin, r.origin);
+    const float o_o = dot(r.origin, r.origin);
     e.a = dot(r.direction, r.direction);
-    e.m2ox = -2.0f * r.origin.x; e.m2oy = -2.0f * r.origin.y; e.m2oz = -2.0f * r.origin.z;
+    e.aox = e.a * (-2.0f * r.origin.x); e.aoy = e.a * (-2.0f * r.origin.y); e.aoz = e.a * (-2.0f * r.origin.z);
+    e.aoo = e.a * o_o;
     return e;
 }
 inline float sphere_constant(float cx, float cy, float cz, float radius) {
@@ -218,8 +220,8 @@ inline float sphere_constant(float cx, float cy, float cz, float radius) {
 }
 inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float> c, float K, float t_min, float t_max) {
     const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
-    const float cc = std::fmaf(c.z, e.m2oz, std::fmaf(c.y, e.m2oy, std::fmaf(c.x, e.m2ox, e.o_o))) + K;
-    const float disc = std::fmaf(h, h, -(e.a * cc));
+    const float m = std::fmaf(K, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
+    const float disc = std::fmaf(h, h, -m);
     if (disc < 0) return t_max;
     const float sqrtd = std::sqrt(disc);
     float root = (h - sqrtd) / e.a;

@@ -15,8 +15,8 @@
 // Closest-hit scan
 //   The sphere index is wave-uniform: records {cx, cy, cz, r*r} come four at a time through the
 //   scalar cache into SGPRs (or from LDS), the next four being fetched while these are tested.
-//   Per sphere a lane spends 3+3 fused multiply-adds for h = d.c - d.o and
-//   c = (|c|^2 - r^2) - 2 c.o + |o|^2, an add, and a multiply + fma for the discriminant
+//   Per sphere a lane spends 3 fused multiply-adds for h = d.c - d.o, 4 for
+//   a*c = a(|c|^2 - r^2) - 2a c.o + a|o|^2 and one for the discriminant h*h - a*c
 //   (main.odin:245-249 with the squares expanded and the per-ray and per-sphere parts
 //   hoisted), all as packed instructions on two spheres at once; a group of four spheres
 //   shares one compare.  Only when some lane's line meets the sphere does the
@@ -345,25 +345,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
         // discriminants (NaNs ignored) is negative in every lane for most groups.
         if constexpr (FMA) {
             // Throughput arithmetic.  The squares of main.odin:245-249 are expanded so that h and
-            // c are dot products of a per-sphere record {centre, K = |centre|^2 - r^2} with
-            // per-ray vectors:   h = d.centre - d.o      c = K - 2 centre.o + |o|^2,
-            // each a chain of three fused multiply-adds (plus one add for K).  Records are stored
-            // as PAIRS of spheres {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} and every operation is a
-            // packed one (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32) on two spheres at once: a
-            // plain VALU instruction with an SGPR source issues at half rate on gfx950, a packed
-            // one with an SGPR-pair source at full rate.  Pad records have K = FLT_MAX: c and a*c
-            // overflow and the discriminant is -inf.
+            // a*c are dot products of a per-sphere record {centre, K = |centre|^2 - r^2} with
+            // per-ray vectors:   h = d.centre - d.o      a*c = a*K - 2a centre.o + a|o|^2,
+            // each a chain of fused multiply-adds (the per-ray factors a*(-2o), a*|o|^2 and a are
+            // formed once per segment), and disc = fma(h, h, -(a*c)): 8 operations per sphere.
+            // Records are stored as PAIRS of spheres {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} and every
+            // operation is a packed one (v_pk_fma_f32) on two spheres at once: a plain VALU
+            // instruction with an SGPR source issues at half rate on gfx950, a packed one with an
+            // SGPR-pair source at full rate.  Pad records have K = FLT_MAX: a*c overflows and the
+            // discriminant is -inf.  `park` receives a*c where the literal modes pass c: only its
+            // sign is used there, and a > 0.
             const float d_o = dot(rd, ro), o_o = dot(ro, ro);
+            const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
             const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
-            const F2 ox2 = {-2.0f * ro.x, -2.0f * ro.x}, oy2 = {-2.0f * ro.y, -2.0f * ro.y}, oz2 = {-2.0f * ro.z, -2.0f * ro.z};
-            const F2 oo2 = {o_o, o_o}, a2 = {a, a};
+            const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {a, a};
             auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
                 const F2 hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
                 const F2 hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
-                const F2 cp = fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))) + p.k;
-                const F2 cq = fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))) + q.k;
-                const F2 dp = fma2(hp, hp, -(a2 * cp));
-                const F2 dq = fma2(hq, hq, -(a2 * cq));
+                const F2 mp = fma2(p.k, a2, fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))));
+                const F2 mq = fma2(q.k, a2, fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))));
+                const F2 dp = fma2(hp, hp, -mp);
+                const F2 dq = fma2(hq, hq, -mq);
                 const float dmax = max_num(max_num(dp.x, dp.y), max_num(dq.x, dq.y));
 #ifdef RT_DIAG_NO_PARK
                 asm volatile("" :: "v"(dmax));
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= 0.0f) != 0ull, 0)) {
 #endif
                     RT_DIAG_COUNT(diag_entries);
-                    park(hp.x, cp.x, dp.x, i); park(hp.y, cp.y, dp.y, i + 1); park(hq.x, cq.x, dq.x, i + 2); park(hq.y, cq.y, dq.y, i + 3);
+                    park(hp.x, mp.x, dp.x, i); park(hp.y, mp.y, dp.y, i + 1); park(hq.x, mq.x, dq.x, i + 2); park(hq.y, mq.y, dq.y, i + 3);
                 }
             };
             // two register sets, A and B, each holding one group: while one is tested the other loads
