@@ -21,7 +21,8 @@
  * Real = float,  FMA = false : the same operation order in f32.
  * Real = float,  FMA = true  : as above, but the ray/sphere test is evaluated in its expanded
  *                              form with fused multiply-adds (ray_sphere_intersection_expanded
- *                              below), and sample colours
+ *                              below), a vector is divided by a scalar as one reciprocal and
+ *                              three products, and sample colours
  *                              are summed exactly in Q32.32 with an f64 mean and square
  *                              root -- the arithmetic of the GPU throughput kernel.
  */
@@ -111,6 +112,13 @@ template <class Real> inline vec3<Real> cross(vec3<Real> a, vec3<Real> b) {
 template <class Real> inline Real magnitude_squared(vec3<Real> v) { return dot(v, v); }
 template <class Real> inline Real magnitude(vec3<Real> v) { return std::sqrt(magnitude_squared(v)); }
 template <class Real> inline vec3<Real> normalize(vec3<Real> v) { return v / magnitude(v); }
+/* GPU throughput arithmetic (FAST): one division, then three multiplications, wherever the
+ * reference divides a vector by a scalar (main.odin:49, :200, :555) */
+template <class Real, bool FAST> inline vec3<Real> scale_down(vec3<Real> v, Real s) {
+    if (FAST) return v * (Real(1) / s);
+    return v / s;
+}
+template <class Real, bool FAST> inline vec3<Real> normalize_as(vec3<Real> v) { return scale_down<Real, FAST>(v, magnitude(v)); }
 /* is_near_zero  main.odin:52-57 */
 template <class Real> inline bool is_near_zero(vec3<Real> v) {
     const Real EPSILON = Real(1e-8);
@@ -141,7 +149,7 @@ template <class Real> inline vec3<Real> refract(vec3<Real> v, vec3<Real> n, Real
 
 /* ---------------------------------------------------------------- random  main.odin:181-223 */
 /* random_unit_vector  main.odin:194-203 (3 draws per candidate: x, y, z) */
-template <class Real> inline vec3<Real> random_unit_vector(draw_stream &g) {
+template <class Real, bool FAST = false> inline vec3<Real> random_unit_vector(draw_stream &g) {
     const Real hi = Real(1) + Real(DBL_EPSILON); /* 1 + math.F64_EPSILON: main.odin:197 */
     vec3<Real> p{};
     Real lsq = 0;
@@ -152,7 +160,7 @@ template <class Real> inline vec3<Real> random_unit_vector(draw_stream &g) {
         lsq = magnitude_squared(p);
         if (Real(0) < lsq && lsq <= Real(1)) break;
     }
-    return p / std::sqrt(lsq);
+    return scale_down<Real, FAST>(p, std::sqrt(lsq));
 }
 /* random_point_on_disk  main.odin:214-223 (2 draws per candidate; z = 0) */
 template <class Real> inline vec3<Real> random_point_on_disk(draw_stream &g) {
@@ -203,8 +211,9 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
  *     h    = fma(cz, dz, fma(cy, dy, fma(cx, dx, -d_o)))
  *     m    = fma(K, a, fma(cz, aoz, fma(cy, aoy, fma(cx, aox, aoo))))        ( = a*c )
  *     disc = fma(h, h, -m)
- * and the roots, range tests and tie rule of main.odin:250-261 unchanged. */
-struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a; };
+ * and the roots (h -+ sqrt(disc)) * (1/a), with the range tests and tie rule of main.odin:250-261
+ * unchanged. */
+struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a, inv_a; };
 inline expanded_ray expand_ray(const ray_t<float> &r) {
     expanded_ray e;
     e.dx = r.direction.x; e.dy = r.direction.y; e.dz = r.direction.z;
@@ -213,6 +222,7 @@ inline expanded_ray expand_ray(const ray_t<float> &r) {
     e.a = dot(r.direction, r.direction);
     e.aox = e.a * (-2.0f * r.origin.x); e.aoy = e.a * (-2.0f * r.origin.y); e.aoz = e.a * (-2.0f * r.origin.z);
     e.aoo = e.a * o_o;
+    e.inv_a = 1.0f / e.a; /* the two roots are formed with this reciprocal instead of two divisions */
     return e;
 }
 inline float sphere_constant(float cx, float cy, float cz, float radius) {
@@ -224,9 +234,9 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
     const float disc = std::fmaf(h, h, -m);
     if (disc < 0) return t_max;
     const float sqrtd = std::sqrt(disc);
-    float root = (h - sqrtd) / e.a;
+    float root = (h - sqrtd) * e.inv_a;
     if (root < t_min || t_max <= root) {
-        root = (h + sqrtd) / e.a;
+        root = (h + sqrtd) * e.inv_a;
         if (root < t_min || t_max <= root) return t_max;
     }
     return root;
@@ -238,29 +248,29 @@ template <class Real> struct material_t { int64_t type; vec3<Real> albedo; Real 
 template <class Real> struct scatter_result { ray_t<Real> ray_out; vec3<Real> attenuation; bool ok; };
 
 /* lambertian_proc  main.odin:292-312 */
-template <class Real>
+template <class Real, bool FAST = false>
 inline scatter_result<Real> lambertian_proc(const material_t<Real> &m, const ray_t<Real> &, const hit_record<Real> &hit, draw_stream &g) {
-    vec3<Real> dir = hit.normal + random_unit_vector<Real>(g);
+    vec3<Real> dir = hit.normal + random_unit_vector<Real, FAST>(g);
     if (is_near_zero(dir)) dir = hit.normal;
     return {{hit.p, dir}, m.albedo, true};
 }
 /* metallic_proc, USE_METAL_FRESNEL = false branch  main.odin:315-323, :348-353 */
-template <class Real>
+template <class Real, bool FAST = false>
 inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
     Real fuzz = m.param1;
-    vec3<Real> dir = normalize(reflect(ray_in.direction, hit.normal));
-    dir = dir + fuzz * random_unit_vector<Real>(g);
+    vec3<Real> dir = normalize_as<Real, FAST>(reflect(ray_in.direction, hit.normal));
+    dir = dir + fuzz * random_unit_vector<Real, FAST>(g);
     return {{hit.p, dir}, m.albedo, dot(dir, hit.normal) > Real(0)};
 }
 /* dielectric_proc  main.odin:356-400 */
-template <class Real>
+template <class Real, bool FAST = false>
 inline scatter_result<Real> dielectric_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
     Real ri = m.param1;
     Real src = ri >= Real(1) ? Real(1) : Real(1) / ri;
     Real dst = ri >= Real(1) ? ri : Real(1);
     if (!hit.front_face) std::swap(src, dst);
     Real rel = src / dst;
-    vec3<Real> unit = normalize(ray_in.direction);
+    vec3<Real> unit = normalize_as<Real, FAST>(ray_in.direction);
     Real cos_theta = dot(-unit, hit.normal);
     cos_theta = std::min(cos_theta, Real(1));
     Real sin2 = Real(1) - cos_theta * cos_theta;
@@ -274,12 +284,12 @@ inline scatter_result<Real> dielectric_proc(const material_t<Real> &m, const ray
     return {{hit.p, dir}, {Real(1), Real(1), Real(1)}, true};
 }
 /* material_scatter  main.odin:403-410 */
-template <class Real>
+template <class Real, bool FAST = false>
 inline scatter_result<Real> material_scatter(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
     switch (m.type) {
-    case RT_MATERIAL_LAMBERTIAN: return lambertian_proc(m, ray_in, hit, g);
-    case RT_MATERIAL_METALLIC: return metallic_proc(m, ray_in, hit, g);
-    default: return dielectric_proc(m, ray_in, hit, g);
+    case RT_MATERIAL_LAMBERTIAN: return lambertian_proc<Real, FAST>(m, ray_in, hit, g);
+    case RT_MATERIAL_METALLIC: return metallic_proc<Real, FAST>(m, ray_in, hit, g);
+    default: return dielectric_proc<Real, FAST>(m, ray_in, hit, g);
     }
 }
 
@@ -292,7 +302,7 @@ template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
 }
 
 /* ---------------------------------------------------------------- the world in Real */
-template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K; /* |center|^2 - r^2, throughput arithmetic only */ };
+template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K, inv_radius; /* |center|^2 - r^2 and 1/r: throughput arithmetic only */ };
 template <class Real> struct camera_t {
     vec3<Real> position, du, dv, top_left, dof_u, dof_v;
     Real dof_angle;
@@ -308,7 +318,8 @@ template <class Real> struct scene_t {
         spheres.resize(ns);
         for (int64_t i = 0; i < ns; ++i)
             spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index,
-                          sphere_constant(static_cast<float>(s[i].center.x), static_cast<float>(s[i].center.y), static_cast<float>(s[i].center.z), static_cast<float>(s[i].radius))};
+                          sphere_constant(static_cast<float>(s[i].center.x), static_cast<float>(s[i].center.y), static_cast<float>(s[i].center.z), static_cast<float>(s[i].radius)),
+                          1.0f / static_cast<float>(s[i].radius)};
         materials.resize(nm);
         for (int64_t i = 0; i < nm; ++i) materials[i] = {m[i].type, cvt<Real>(m[i].albedo), static_cast<Real>(m[i].param1)};
         cam = {cvt<Real>(c->position), cvt<Real>(c->pixel_delta_u), cvt<Real>(c->pixel_delta_v),
@@ -359,11 +370,12 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             const material_t<Real> &mat = sc.materials[sp.material_index];
             hit_record<Real> hit;
             hit.p = ray.origin + closest_t * ray.direction;
-            hit.normal = (hit.p - sp.center) / sp.radius;
+            if constexpr (FMA) hit.normal = (hit.p - sp.center) * static_cast<Real>(sp.inv_radius);
+            else hit.normal = (hit.p - sp.center) / sp.radius;
             hit.front_face = dot(ray.direction, hit.normal) < Real(0);
             hit.normal = hit.front_face ? hit.normal : -hit.normal;
             draw_stream sg(keys, pixel, sample, static_cast<uint32_t>(bounce) + 1u);
-            scatter_result<Real> s = material_scatter(mat, ray, hit, sg);
+            scatter_result<Real> s = material_scatter<Real, FMA>(mat, ray, hit, sg);
             if (s.ok) {
                 ray = s.ray_out;
                 sample_color = sample_color * s.attenuation;
@@ -372,7 +384,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
                 break;
             }
         } else {
-            ray.direction = normalize(ray.direction);
+            ray.direction = normalize_as<Real, FMA>(ray.direction);
             sample_color = sample_color * background_color(ray);
             break;
         }
@@ -548,7 +560,7 @@ int32_t oracle_material_scatter(int32_t precision, const rt_material *m, const d
     ray_t<float> r{{(float)ray_o[0], (float)ray_o[1], (float)ray_o[2]}, {(float)ray_d[0], (float)ray_d[1], (float)ray_d[2]}};
     hit_record<float> h{{(float)hit_p[0], (float)hit_p[1], (float)hit_p[2]},
                         {(float)hit_normal[0], (float)hit_normal[1], (float)hit_normal[2]}, front_face != 0};
-    auto s = material_scatter(mm, r, h, g);
+    auto s = precision == RT_PRECISION_F32 ? material_scatter<float, true>(mm, r, h, g) : material_scatter<float, false>(mm, r, h, g);
     double tmp[9] = {s.ray_out.origin.x, s.ray_out.origin.y, s.ray_out.origin.z, s.ray_out.direction.x, s.ray_out.direction.y,
                      s.ray_out.direction.z, s.attenuation.x, s.attenuation.y, s.attenuation.z};
     std::memcpy(out, tmp, sizeof tmp);

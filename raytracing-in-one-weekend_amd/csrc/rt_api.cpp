@@ -82,6 +82,7 @@ struct rt_world_s {
     void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
     void *rec32k = nullptr;                     // {cx, cy, cz, |c|^2 - r*r}: the throughput kernel's records
     void *rad32 = nullptr, *rad64 = nullptr;
+    void *rad32inv = nullptr;                   // 1/radius in f32, the throughput kernel's hit normal is (p - c) * (1/r)
     int32_t *sphere_material = nullptr;
     void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
     int32_t *material_type = nullptr;
@@ -211,7 +212,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     // record has r*r = -inf, which makes its discriminant -inf (or NaN): never a candidate
     const size_t ns_pad = (ns + rtk::SCAN_STEP - 1) / rtk::SCAN_STEP * rtk::SCAN_STEP;
     const size_t ns_alloc = ns_pad + rtk::GROUP;
-    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32k(4 * ns_alloc, 0.0f), rad32(ns), mat32(4 * nm);
+    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32k(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
     // throughput records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
     auto pair_slot = [](size_t i, int component) { return 8 * (i / 2) + 2 * component + (i % 2); };
@@ -227,7 +228,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         rec32k[pair_slot(i, 3)] = static_cast<float>(static_cast<double>(rec32[4 * i]) * rec32[4 * i] + static_cast<double>(rec32[4 * i + 1]) * rec32[4 * i + 1] +
                                                static_cast<double>(rec32[4 * i + 2]) * rec32[4 * i + 2] - static_cast<double>(r) * r);
         rec64[4 * i + 0] = s.center.x; rec64[4 * i + 1] = s.center.y; rec64[4 * i + 2] = s.center.z; rec64[4 * i + 3] = s.radius * s.radius;
-        rad32[i] = r; rad64[i] = s.radius;
+        rad32[i] = r; rad64[i] = s.radius; rad32inv[i] = 1.0f / r;
         smat[i] = static_cast<int32_t>(s.material_index);
     }
     for (size_t i = 0; i < nm; ++i) {
@@ -253,6 +254,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     if (e == hipSuccess) e = upload(&w->rec64, rec64.data(), rec64.size() * 8);
     if (e == hipSuccess) e = upload(&w->rad32, rad32.data(), rad32.size() * 4);
     if (e == hipSuccess) e = upload(&w->rad64, rad64.data(), rad64.size() * 8);
+    if (e == hipSuccess) e = upload(&w->rad32inv, rad32inv.data(), rad32inv.size() * 4);
     if (e == hipSuccess) e = upload(reinterpret_cast<void **>(&w->sphere_material), smat.data(), smat.size() * 4);
     if (e == hipSuccess) e = upload(&w->mat32, mat32.data(), mat32.size() * 4);
     if (e == hipSuccess) e = upload(&w->mat64, mat64.data(), mat64.size() * 8);
@@ -279,7 +281,7 @@ int32_t rt_world_destroy(rt_world *w) {
     if (w == nullptr) return RT_OK;
     DeviceGuard guard;
     (void)guard.enter(w->device);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue};
+    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
@@ -332,7 +334,7 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     rtk::RenderParams p{};
     p.sphere_rec = f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32);
     p.sphere_center = f64 ? world->rec64 : world->rec32;
-    p.sphere_radius = f64 ? world->rad64 : world->rad32;
+    p.sphere_radius = f64 ? world->rad64 : (precision == RT_PRECISION_F32 ? world->rad32inv : world->rad32);
     p.sphere_material = world->sphere_material;
     p.material_rec = f64 ? world->mat64 : world->mat32;
     p.material_type = world->material_type;

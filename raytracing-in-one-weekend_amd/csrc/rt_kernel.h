@@ -42,7 +42,7 @@ struct RenderParams {
     const void *sphere_rec;     // scan records: float4 / double4 {cx, cy, cz, r*r}; throughput mode: per PAIR of spheres
                                 // {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} with K = |c|^2 - r*r
     const void *sphere_center;  // float4 / double4 {cx, cy, cz, r*r}: the centre is read from here on a hit
-    const void *sphere_radius;  // per sphere radius, float / double
+    const void *sphere_radius;  // per sphere radius, float / double (throughput mode: 1/radius)
     const int32_t *sphere_material;
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
     const int32_t *material_type;

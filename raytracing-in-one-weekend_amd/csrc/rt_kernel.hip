@@ -58,7 +58,13 @@ __device__ __forceinline__ float abs_rn(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_rn(double x) { return __builtin_fabs(x); }
 template <typename Real> __device__ __forceinline__ Real min_std(Real a, Real b) { return (b < a) ? b : a; } // std::min
 template <typename Real> __device__ __forceinline__ Real max_std(Real a, Real b) { return (a < b) ? b : a; } // std::max
-template <typename Real> __device__ __forceinline__ V3<Real> normalize(V3<Real> v) { return v / sqrt_rn(dot(v, v)); } // main.odin:48-50
+// A vector divided by a scalar (main.odin:49, :200, :555): three divisions in the literal modes,
+// one reciprocal and three products in the throughput arithmetic (FAST).
+template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> scale_down(V3<Real> v, Real s) {
+    if (FAST) return v * (Real(1) / s);
+    return v / s;
+}
+template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> normalize(V3<Real> v) { return scale_down<Real, FAST>(v, sqrt_rn(dot(v, v))); } // main.odin:48-50
 
 template <typename Real> struct Lim;
 template <> struct Lim<float> { static constexpr float max_v = 3.402823466e+38f; static constexpr float eps = 1.1920928955078125e-07f; };
@@ -93,7 +99,7 @@ struct Draws {
 };
 
 // random_unit_vector (main.odin:194-203)
-template <typename Real> __device__ __forceinline__ V3<Real> random_unit_vector(Draws &g) {
+template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> random_unit_vector(Draws &g) {
     const Real hi = Real(1) + Real(2.220446049250313e-16); // 1 + F64_EPSILON, rounds to 1 in f32
     V3<Real> p = {Real(0), Real(0), Real(0)};
     Real lsq = Real(0);
@@ -104,7 +110,7 @@ template <typename Real> __device__ __forceinline__ V3<Real> random_unit_vector(
         lsq = dot(p, p);
         if (Real(0) < lsq && lsq <= Real(1)) break;
     }
-    return p / sqrt_rn(lsq);
+    return scale_down<Real, FAST>(p, sqrt_rn(lsq));
 }
 
 // ----------------------------------------------------------------------------- optics
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
 
         // ---------------- closest-hit scan (main.odin:536-546 with :240-263 inlined)
         const Real a = dot(rd, rd);
+        const Real inv_a = FMA ? Real(1) / a : Real(0); // throughput arithmetic: roots are (h -+ sqrt(disc)) * (1/a)
         const Real t_min = static_cast<Real>(0.001); // SHADOW_ACNE_RAY_OFFSET
         Real closest = Lim<Real>::max_v;
         int hit = -1;
@@ -318,10 +325,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             RT_DIAG_COUNT(diag_resolves);
             // main.odin:252-261 for the parked candidate, then :542-545
             Real sq = sqrt_rn(pend_disc);
-            Real root = (pend_h - sq) / a;
+            Real root = FMA ? (pend_h - sq) * inv_a : (pend_h - sq) / a;
             bool rejected = (root < t_min) || (closest <= root);
             if (rejected) {
-                root = (pend_h + sq) / a;
+                root = FMA ? (pend_h + sq) * inv_a : (pend_h + sq) / a;
                 rejected = (root < t_min) || (closest <= root);
             }
             if (!rejected && root < closest) { closest = root; hit = pend; }
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             // hit record (main.odin:553-557)
             const V3<Real> center = {sp.x, sp.y, sp.z};
             const V3<Real> p = ro + closest * rd;
-            V3<Real> nrm = (p - center) / radius;
+            V3<Real> nrm = FMA ? (p - center) * radius : (p - center) / radius; // throughput mode: the array holds 1/r
             const bool front = dot(rd, nrm) < Real(0);
             nrm = front ? nrm : -nrm;
             Draws g(ks, wp, static_cast<uint32_t>(bounce) + 1u);
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 Real dst = (ri >= Real(1)) ? ri : Real(1);
                 if (!front) { Real t = src; src = dst; dst = t; }
                 const Real rel = src / dst;
-                const V3<Real> unit = normalize(rd);
+                const V3<Real> unit = normalize<Real, FMA>(rd);
                 Real cos_theta = dot(-unit, nrm);
                 cos_theta = min_std(cos_theta, Real(1));
                 const Real sin2 = Real(1) - cos_theta * cos_theta;
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 dir = do_reflect ? reflect(unit, nrm) : refract(unit, nrm, rel);
                 atten = {Real(1), Real(1), Real(1)};
             } else {
-                const V3<Real> ruv = random_unit_vector<Real>(g);
+                const V3<Real> ruv = random_unit_vector<Real, FMA>(g);
                 if (mtype == 0) {
                     // lambertian_proc (main.odin:292-312)
                     dir = nrm + ruv;
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                     if (abs_rn(dir.x) <= EPS && abs_rn(dir.y) <= EPS && abs_rn(dir.z) <= EPS) dir = nrm;
                 } else {
                     // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
-                    dir = normalize(reflect(rd, nrm));
+                    dir = normalize<Real, FMA>(reflect(rd, nrm));
                     dir = dir + m.w * ruv;
                     ok = dot(dir, nrm) > Real(0);
                 }
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             }
         } else {
             // background (main.odin:570-572, :412-418): lerp(a, b, t) = a*(1-t) + b*t
-            const V3<Real> d = normalize(rd);
+            const V3<Real> d = normalize<Real, FMA>(rd);
             const Real t = Real(0.5) * (d.y + Real(1));
             const V3<Real> wa = {Real(1), Real(1), Real(1)};
             const V3<Real> wb = {static_cast<Real>(0.5), static_cast<Real>(0.7), static_cast<Real>(1.0)};
