@@ -218,3 +218,35 @@ def test_against_committed_golden_fixtures(rt, name):
     rel = np.abs(linear - g64["linear"]) / np.maximum(g64["linear"], 1e-3)
     assert np.mean(rel.max(axis=2) <= 1e-4) > 0.97
     assert np.mean(np.all(rt.quantize_rgb8(image) == rt.quantize_rgb8(g64["image"]), axis=2)) > 0.97
+
+
+def test_stochastic_mode_noise_band(rt, oracle):
+    """Stochastic mode: RMSE of a 64-spp GPU render against a 16384-spp converged image must sit in
+    the noise band of the reference algorithm itself, measured by rendering the same 64 spp with
+    the f64 CPU restatement (different seeds throughout)."""
+    cs, cam, sph, mat = scene(rt, "dev", 96, 16384)
+    w, h = cs.image_width, cs.image_height
+    converged = np.zeros((h, w, 3))
+    lin_conv = np.zeros((h, w, 3))
+    rt.render_region(converged, (0, 0, w, h), cam, sph, mat, seed=1234, linear_out=lin_conv)
+    cs.samples_per_pixel = 64
+    cam = rt.calculate_camera_render_data(cs)
+
+    def rmse(lin):
+        return float(np.sqrt(np.mean((lin - lin_conv) ** 2)))
+
+    gpu = []
+    for k in range(4):
+        img, lin = np.zeros((h, w, 3)), np.zeros((h, w, 3))
+        rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=50 + k, rng_mode=rt.RNG_STOCHASTIC, linear_out=lin)
+        gpu.append(rmse(lin))
+    cpu = [rmse(oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=900 + k, threads=8)["linear"]) for k in range(3)]
+    print("RMSE vs converged: GPU f32 stochastic", gpu, "CPU f64 restatement", cpu)
+    band = (0.85 * min(cpu), 1.15 * max(cpu))
+    assert all(band[0] <= g <= band[1] for g in gpu)
+    # and the noise falls like 1/sqrt(spp): 4x the samples, half the error
+    cs.samples_per_pixel = 256
+    cam4 = rt.calculate_camera_render_data(cs)
+    img, lin = np.zeros((h, w, 3)), np.zeros((h, w, 3))
+    rt.render_region(img, (0, 0, w, h), cam4, sph, mat, seed=77, linear_out=lin)
+    assert 0.4 < rmse(lin) / np.mean(gpu) < 0.62
