@@ -81,7 +81,9 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 
 /* arithmetic the kernel computes in */
 #define RT_PRECISION_F32 0         /* f32 paths, fused multiply-adds in the ray/sphere test, exact Q32.32 sample
-                                      sums, f64 mean and square root (throughput path)                       */
+                                      sums, f64 mean and square root (throughput path).  The sphere a scattered
+                                      segment starts on is tested with c = 0 (main.odin:247 evaluates to ~1e-15
+                                      there in f64; its f32 rounding would give spurious self-intersections)   */
 #define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
 #define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
 

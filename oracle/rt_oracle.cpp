@@ -242,6 +242,22 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
     return root;
 }
 
+/* Throughput arithmetic, the sphere a scattered segment starts on.  Its origin is the hit point of
+ * the previous segment, so c = |center - o|^2 - r^2 is zero up to the rounding of that hit
+ * point; in f64 the reference's expression sees |c| ~ 1e-15 and its near root falls below t_min,
+ * in f32 the rounding of c is large enough to produce spurious hits at t just above t_min for
+ * short or grazing directions.  The test therefore takes c = 0 for this one sphere: the roots of
+ * main.odin:249-258 become 0 and 2h/a, of which only the second can lie in [t_min, t_max), and
+ * only for h > 0 (a segment that runs through the inside of the sphere).  h is the same fused
+ * chain as in ray_sphere_intersection_expanded.  trace_sample tests this sphere first and leaves
+ * it out of the scan over the list. */
+inline float ray_sphere_intersection_from_surface(const expanded_ray &e, vec3<float> c, float t_min, float t_max) {
+    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
+    const float root = (h + h) * e.inv_a;
+    if (h > 0 && root >= t_min && root < t_max) return root;
+    return t_max;
+}
+
 /* ---------------------------------------------------------------- materials  main.odin:268-410 */
 template <class Real> struct material_t { int64_t type; vec3<Real> albedo; Real param1; };
 
@@ -348,6 +364,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
     ray_t<Real> ray{ray_origin, pixel_sample_position - ray_origin};
     vec3<Real> sample_color{Real(1), Real(1), Real(1)};
     const int64_t n = static_cast<int64_t>(sc.spheres.size());
+    int64_t start_sphere = -1; /* throughput arithmetic: the sphere this segment's origin lies on (none for a camera ray) */
     for (int64_t bounce = 0; bounce <= sc.max_ray_bounces; ++bounce) { /* 0..=max  main.odin:535 */
         ++*segments;
         Real closest_t = std::numeric_limits<Real>::max();
@@ -355,7 +372,12 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
         const Real SHADOW_ACNE_RAY_OFFSET = Real(0.001);
         if constexpr (FMA) {
             const expanded_ray e = expand_ray(ray);
+            if (start_sphere >= 0) {
+                Real t = ray_sphere_intersection_from_surface(e, sc.spheres[start_sphere].center, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                if (t < closest_t) { closest_t = t; hit_index = start_sphere; }
+            }
             for (int64_t i = 0; i < n; ++i) {
+                if (i == start_sphere) continue;
                 Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, SHADOW_ACNE_RAY_OFFSET, closest_t);
                 if (t < closest_t) { closest_t = t; hit_index = i; }
             }
@@ -377,6 +399,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             draw_stream sg(keys, pixel, sample, static_cast<uint32_t>(bounce) + 1u);
             scatter_result<Real> s = material_scatter<Real, FMA>(mat, ray, hit, sg);
             if (s.ok) {
+                start_sphere = hit_index;
                 ray = s.ray_out;
                 sample_color = sample_color * s.attenuation;
             } else {

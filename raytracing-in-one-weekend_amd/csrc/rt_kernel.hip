@@ -230,6 +230,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
     V3<Real> acc = {Real(0), Real(0), Real(0)};                                  // pixel_color (literal modes)
     int bounce = 0;
     bool fresh = true;
+    // throughput arithmetic: the sphere the current segment starts on (-1 for a camera ray) and its centre
+    int start_sphere = -1;
+    V3<Real> start_center = {Real(0), Real(0), Real(0)};
     uint32_t segments = 0, started = 0;
 #ifdef RT_DIAG_COUNTERS
     // diagnostic build: how often the scan leaves its straight-line code
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             rd = psp - ro;
             color = {Real(1), Real(1), Real(1)};
             bounce = 0;
+            start_sphere = -1;
             fresh = false;
         }
 
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             if (__builtin_amdgcn_ballot_w64(disc >= Real(0)) != 0ull) {
                 // A line that meets the sphere only behind the origin (h <= 0) while the origin
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
-                const bool cand = (disc >= Real(0)) && ((h > Real(0)) || (cc < Real(0)));
+                // (the sphere the segment starts on was tested before the scan)
+                const bool cand = (disc >= Real(0)) && ((h > Real(0)) || (cc < Real(0))) && (!FMA || i != start_sphere);
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
                 }
@@ -363,6 +368,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             // discriminant is -inf.  `park` receives a*c where the literal modes pass c: only its
             // sign is used there, and a > 0.
             const float d_o = dot(rd, ro), o_o = dot(ro, ro);
+            // The sphere this segment starts on: its origin is the previous hit point, so c is zero
+            // up to the rounding of that point.  The reference's f64 arithmetic sees |c| ~ 1e-15
+            // and its near root falls below t_min; in f32 the rounding of c is large enough to give
+            // spurious hits just above t_min for short or grazing directions.  Take c = 0 for this
+            // sphere: the roots of main.odin:249-258 become 0 and 2h/a, and only the second can be
+            // a hit, for h > 0 (a segment through the inside).  It is tested first and left out
+            // of the scan.
+            if (start_sphere >= 0) {
+                const float h = __builtin_fmaf(start_center.z, rd.z, __builtin_fmaf(start_center.y, rd.y, __builtin_fmaf(start_center.x, rd.x, -d_o)));
+                const float root = (h + h) * inv_a;
+                if (h > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
+            }
             const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
             const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
             const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {a, a};
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             }
             if (ok) {
                 ro = p; rd = dir;
+                start_sphere = hit; start_center = center;
                 color = color * atten;
                 ++bounce;
                 ended = bounce > P.max_bounces; // `for _ in 0..=max_ray_bounces` ran out: colour is kept (main.odin:535)

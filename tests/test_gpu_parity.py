@@ -124,11 +124,35 @@ def test_f32_against_f64_reference_criteria(rt, oracle):
     frac_1e4 = float(np.mean(rel.max(axis=2) <= 1e-4))
     frac_8bit = float(np.mean(np.all(q_gpu == q_ref, axis=2)))
     print(f"f32 GPU vs f64 oracle: {frac_1e4:.4f} of pixels within 1e-4 rel, {frac_8bit:.4f} identical at 8 bit")
-    assert frac_1e4 > 0.90 and frac_8bit > 0.95
+    assert frac_1e4 > 0.99 and frac_8bit > 0.99
     # and the f64 GPU mode meets the spec's criteria outright
     image64, linear64, _ = gpu_render(rt, cs, cam, sph, mat, seed=21, precision=1)
     assert np.array_equal(linear64, ref["linear"])
     assert np.array_equal(rt.quantize_rgb8(image64), q_ref)
+
+
+@pytest.mark.parametrize("name,min_1e4,min_8bit", [("two", 0.9995, 0.9995), ("dev", 0.995, 0.998)])
+def test_named_parity_configs_f32_against_f64(rt, oracle, name, min_1e4, min_8bit):
+    """The two small benchmark configurations (400x225, 100 spp, depth 50), GPU f32 throughput
+    mode against the f64 restatement of the reference with the same draws: share of pixels within
+    1e-4 relative in linear space, and share of identical 8-bit pixels.  Paths that differ are
+    long ones (ten and more bounces between the glass shell and the bubble inside it), where f32
+    rounding has been amplified by every curved surface on the way."""
+    cs, cam, sph, mat = scene(rt, name, 400, 100)
+    w, h = cs.image_width, cs.image_height
+    assert (w, h) == (400, 225) and cs.max_ray_bounces == 50
+    image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=3)
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=3, threads=8)
+    rel = np.abs(linear - ref["linear"]) / np.maximum(ref["linear"], 1e-12)
+    frac_1e4 = float(np.mean(rel.max(axis=2) <= 1e-4))
+    frac_8bit = float(np.mean(np.all(rt.quantize_rgb8(image) == oracle.quantize_rgb8(ref["image"]), axis=2)))
+    seg_ratio = int(stats[0]) / int(ref["stats"][0])
+    print(f"{name}: {frac_1e4:.5f} within 1e-4, {frac_8bit:.5f} identical at 8 bit, segments f32/f64 {seg_ratio:.6f}")
+    assert frac_1e4 >= min_1e4 and frac_8bit >= min_8bit
+    assert abs(seg_ratio - 1.0) < 1e-3  # no spurious self-intersections: both trace the same number of segments
+    # the f64 mode is the reference's arithmetic, and with one chunk its summation order: identical
+    image64, linear64, _ = gpu_render(rt, cs, cam, sph, mat, seed=3, precision=1, sample_chunks=1)
+    assert np.array_equal(linear64, ref["linear"]) and np.array_equal(image64, ref["image"])
 
 
 def test_device_resident_strips_and_sample_split(rt, oracle):
@@ -216,8 +240,8 @@ def test_against_committed_golden_fixtures(rt, name):
     # the spec's criteria, f32 throughput mode against the f64 fixture
     image, linear, _ = gpu_render(rt, cs, cam, sph, mat, seed=seed)
     rel = np.abs(linear - g64["linear"]) / np.maximum(g64["linear"], 1e-3)
-    assert np.mean(rel.max(axis=2) <= 1e-4) > 0.97
-    assert np.mean(np.all(rt.quantize_rgb8(image) == rt.quantize_rgb8(g64["image"]), axis=2)) > 0.97
+    assert np.mean(rel.max(axis=2) <= 1e-4) > 0.99
+    assert np.mean(np.all(rt.quantize_rgb8(image) == rt.quantize_rgb8(g64["image"]), axis=2)) > 0.99
 
 
 def test_stochastic_mode_noise_band(rt, oracle):
