@@ -19,12 +19,15 @@
  * Real = double, FMA = false : the reference's arithmetic as written (v3 :: [3]f64,
  *                              main.odin:19; LLVM does not contract a*b+c without fast-math).
  * Real = float,  FMA = false : the same operation order in f32.
- * Real = float,  FMA = true  : as above, but the ray/sphere test is evaluated in its expanded
- *                              form with fused multiply-adds (ray_sphere_intersection_expanded
- *                              below), a vector is divided by a scalar as one reciprocal and
- *                              three products, and sample colours
- *                              are summed exactly in Q32.32 with an f64 mean and square
- *                              root -- the arithmetic of the GPU throughput kernel.
+ * Real = float,  FMA = true  : as above, but the ray/sphere test is the two-stage form of
+ *                              ray_sphere_intersection_expanded below (candidates from an
+ *                              expanded discriminant in fused multiply-adds, their roots from
+ *                              the centre-to-line vector), the sphere a scattered segment
+ *                              starts on is tested with c = 0
+ *                              (ray_sphere_intersection_from_surface), a vector is divided by
+ *                              a scalar as one reciprocal and three products, and sample
+ *                              colours are summed exactly in Q32.32 with an f64 mean and
+ *                              square root -- the arithmetic of the GPU throughput kernel.
  */
 #include <algorithm>
 #include <atomic>
@@ -199,9 +202,10 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
     return t;
 }
 
-/* The ray/sphere test of the GPU throughput arithmetic (f32).  Same algebra as
- * main.odin:245-249 with the squares expanded so that both h and a*c are dot products of a
- * per-sphere vector with a per-ray vector:
+/* The ray/sphere test of the GPU throughput arithmetic (f32), in two stages.
+ *
+ * Stage 1, every sphere: the discriminant of main.odin:245-249 with the squares expanded so that
+ * both h and a*c are dot products of a per-sphere vector with a per-ray vector:
  *     h   = d.(center - o)            = d.center - d.o
  *     a*c = a(|center - o|^2 - r^2)   = a(|center|^2 - r^2) - 2a center.o + a|o|^2
  * Per sphere: K = |center|^2 - r^2 (formed in f64 from the f32 centre and radius, rounded to
@@ -211,9 +215,19 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
  *     h    = fma(cz, dz, fma(cy, dy, fma(cx, dx, -d_o)))
  *     m    = fma(K, a, fma(cz, aoz, fma(cy, aoy, fma(cx, aox, aoo))))        ( = a*c )
  *     disc = fma(h, h, -m)
- * and the roots (h -+ sqrt(disc)) * (1/a), with the range tests and tie rule of main.odin:250-261
- * unchanged. */
-struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a, inv_a; };
+ * A sphere is a candidate when disc >= 0, unless h <= 0 and m >= 0 (the line meets it only
+ * behind an origin that lies outside it: both roots <= 0).  disc is the difference of two
+ * numbers of size a*|center - o|^2, so it selects candidates and nothing more.
+ *
+ * Stage 2, candidates only: the roots from the vector l that runs from the centre to the
+ * line's closest point, whose length is of the size of the radius, so that the rounding error
+ * scales with the sphere and not with its distance:
+ *     oc = center - o,   q = fma(ocz, dz, fma(ocy, dy, ocx*dx)) * (1/a),
+ *     l  = fma(-q, d, oc) per component,   D = r*r - fma(lz, lz, fma(ly, ly, lx*lx)),
+ *     roots q -+ sqrt(D * (1/a)),
+ * which is main.odin:249-258 with disc = a*D; the range tests and the order of the two roots
+ * (main.odin:250-261) are unchanged.  r*r is the f32 product of the f32 radius. */
+struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a, inv_a; vec3<float> o; };
 inline expanded_ray expand_ray(const ray_t<float> &r) {
     expanded_ray e;
     e.dx = r.direction.x; e.dy = r.direction.y; e.dz = r.direction.z;
@@ -222,21 +236,30 @@ inline expanded_ray expand_ray(const ray_t<float> &r) {
     e.a = dot(r.direction, r.direction);
     e.aox = e.a * (-2.0f * r.origin.x); e.aoy = e.a * (-2.0f * r.origin.y); e.aoz = e.a * (-2.0f * r.origin.z);
     e.aoo = e.a * o_o;
-    e.inv_a = 1.0f / e.a; /* the two roots are formed with this reciprocal instead of two divisions */
+    e.inv_a = 1.0f / e.a; /* one reciprocal per segment instead of a division per root */
+    e.o = r.origin;
     return e;
 }
 inline float sphere_constant(float cx, float cy, float cz, float radius) {
     return static_cast<float>(static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz - static_cast<double>(radius) * radius);
 }
-inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float> c, float K, float t_min, float t_max) {
+inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float> c, float K, float radius, float t_min, float t_max) {
+    /* stage 1 */
     const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
     const float m = std::fmaf(K, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
     const float disc = std::fmaf(h, h, -m);
-    if (disc < 0) return t_max;
-    const float sqrtd = std::sqrt(disc);
-    float root = (h - sqrtd) * e.inv_a;
+    if (!(disc >= 0)) return t_max;
+    if (!(h > 0 || m < 0)) return t_max;
+    /* stage 2 */
+    const float ocx = c.x - e.o.x, ocy = c.y - e.o.y, ocz = c.z - e.o.z;
+    const float q = std::fmaf(ocz, e.dz, std::fmaf(ocy, e.dy, ocx * e.dx)) * e.inv_a;
+    const float lx = std::fmaf(-q, e.dx, ocx), ly = std::fmaf(-q, e.dy, ocy), lz = std::fmaf(-q, e.dz, ocz);
+    const float D = radius * radius - std::fmaf(lz, lz, std::fmaf(ly, ly, lx * lx));
+    if (!(D >= 0)) return t_max;
+    const float s = std::sqrt(D * e.inv_a);
+    float root = q - s;
     if (root < t_min || t_max <= root) {
-        root = (h + sqrtd) * e.inv_a;
+        root = q + s;
         if (root < t_min || t_max <= root) return t_max;
     }
     return root;
@@ -248,13 +271,14 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
  * in f32 the rounding of c is large enough to produce spurious hits at t just above t_min for
  * short or grazing directions.  The test therefore takes c = 0 for this one sphere: the roots of
  * main.odin:249-258 become 0 and 2h/a, of which only the second can lie in [t_min, t_max), and
- * only for h > 0 (a segment that runs through the inside of the sphere).  h is the same fused
- * chain as in ray_sphere_intersection_expanded.  trace_sample tests this sphere first and leaves
+ * only for h > 0 (a segment that runs through the inside of the sphere).  q = h/a is formed as in
+ * stage 2 of ray_sphere_intersection_expanded.  trace_sample tests this sphere first and leaves
  * it out of the scan over the list. */
 inline float ray_sphere_intersection_from_surface(const expanded_ray &e, vec3<float> c, float t_min, float t_max) {
-    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
-    const float root = (h + h) * e.inv_a;
-    if (h > 0 && root >= t_min && root < t_max) return root;
+    const float ocx = c.x - e.o.x, ocy = c.y - e.o.y, ocz = c.z - e.o.z;
+    const float q = std::fmaf(ocz, e.dz, std::fmaf(ocy, e.dy, ocx * e.dx)) * e.inv_a;
+    const float root = q + q;
+    if (q > 0 && root >= t_min && root < t_max) return root;
     return t_max;
 }
 
@@ -378,7 +402,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             }
             for (int64_t i = 0; i < n; ++i) {
                 if (i == start_sphere) continue;
-                Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
                 if (t < closest_t) { closest_t = t; hit_index = i; }
             }
         } else {
@@ -559,7 +583,7 @@ double oracle_ray_sphere_intersection(int32_t precision, const double *o, const 
     ray_t<float> r{{(float)o[0], (float)o[1], (float)o[2]}, {(float)d[0], (float)d[1], (float)d[2]}};
     vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
     if (precision == RT_PRECISION_F32)
-        return ray_sphere_intersection_expanded(expand_ray(r), cf, sphere_constant(cf.x, cf.y, cf.z, (float)radius), (float)t_min, (float)t_max);
+        return ray_sphere_intersection_expanded(expand_ray(r), cf, sphere_constant(cf.x, cf.y, cf.z, (float)radius), (float)radius, (float)t_min, (float)t_max);
     return ray_sphere_intersection<float>(r, cf, (float)radius, (float)t_min, (float)t_max);
 }
 

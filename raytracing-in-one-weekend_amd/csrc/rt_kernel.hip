@@ -327,15 +327,40 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
 
         auto resolve = [&]() {
             RT_DIAG_COUNT(diag_resolves);
-            // main.odin:252-261 for the parked candidate, then :542-545
-            Real sq = sqrt_rn(pend_disc);
-            Real root = FMA ? (pend_h - sq) * inv_a : (pend_h - sq) / a;
-            bool rejected = (root < t_min) || (closest <= root);
-            if (rejected) {
-                root = FMA ? (pend_h + sq) * inv_a : (pend_h + sq) / a;
-                rejected = (root < t_min) || (closest <= root);
+            if constexpr (FMA) {
+                // Throughput arithmetic: the scan's discriminant h^2 - a*c is the difference of two
+                // numbers of size a*|centre - o|^2 and only selects candidates.  A candidate's roots
+                // come from the vector l from the centre to the line's closest point, whose length
+                // is at most of the size of the radius:
+                //     oc = centre - o,  q = (d.oc)/a,  l = oc - q*d,  D = r^2 - |l|^2,
+                //     roots q -+ sqrt(D/a)            (main.odin:249-258 with disc = a*D),
+                // so their rounding error scales with the sphere, not with its distance.
+                const R4 sp = static_cast<const R4 *>(P.sphere_center)[pend]; // {centre, r*r}
+                const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
+                const Real q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a;
+                const Real lx = fma_rn(-q, rd.x, ocx), ly = fma_rn(-q, rd.y, ocy), lz = fma_rn(-q, rd.z, ocz);
+                const Real D = sp.w - fma_rn(lz, lz, fma_rn(ly, ly, lx * lx));
+                if (D >= Real(0)) {
+                    const Real sq = sqrt_rn(D * inv_a);
+                    Real root = q - sq;
+                    bool rejected = (root < t_min) || (closest <= root);
+                    if (rejected) {
+                        root = q + sq;
+                        rejected = (root < t_min) || (closest <= root);
+                    }
+                    if (!rejected && root < closest) { closest = root; hit = pend; }
+                }
+            } else {
+                // main.odin:252-261 for the parked candidate, then :542-545
+                Real sq = sqrt_rn(pend_disc);
+                Real root = (pend_h - sq) / a;
+                bool rejected = (root < t_min) || (closest <= root);
+                if (rejected) {
+                    root = (pend_h + sq) / a;
+                    rejected = (root < t_min) || (closest <= root);
+                }
+                if (!rejected && root < closest) { closest = root; hit = pend; }
             }
-            if (!rejected && root < closest) { closest = root; hit = pend; }
             pend = -1;
         };
         // the uncommon continuation for one sphere: some lane's line meets it
@@ -348,7 +373,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
                 }
-                if (cand) { pend_h = h; pend_disc = disc; pend = i; RT_DIAG_COUNT(diag_parked); }
+                if (cand) {
+                    if constexpr (!FMA) { pend_h = h; pend_disc = disc; }
+                    pend = i;
+                    RT_DIAG_COUNT(diag_parked);
+                }
             }
         };
         // The record array is padded to a multiple of SCAN_STEP with records that can never be
@@ -376,9 +405,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             // a hit, for h > 0 (a segment through the inside).  It is tested first and left out
             // of the scan.
             if (start_sphere >= 0) {
-                const float h = __builtin_fmaf(start_center.z, rd.z, __builtin_fmaf(start_center.y, rd.y, __builtin_fmaf(start_center.x, rd.x, -d_o)));
-                const float root = (h + h) * inv_a;
-                if (h > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
+                const float ocx = start_center.x - ro.x, ocy = start_center.y - ro.y, ocz = start_center.z - ro.z;
+                const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a; // (d.oc)/a as in `resolve`
+                const float root = q + q;
+                if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
             const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
             const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
