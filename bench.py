@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--partition", default="samples", choices=["samples", "rows"])
     ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds"])
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--verify", action="store_true", help="after timing, rank 0 re-renders the frame in one rt_render_region call and compares bitwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -60,9 +61,42 @@ def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
     r = o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=spp, threads=cores)
     dt = time.perf_counter() - t0
     samples = width * height * spp
+    # one thread, the reference's default (RENDER_MULTITHREADED = false, main.odin:14): every 2nd row of one 1-spp frame
+    rows = list(range(0, height, 2))
+    t0 = time.perf_counter()
+    for v in rows:
+        o.render_region(width, height, (0, v, width, v + 1), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"full {width}x{height} frame at {spp} spp ({samples} samples, {dt:.1f} s), f64, {cores} threads over rows",
-            "segments_per_sample": float(r["stats"][0]) / samples}
+            "segments_per_sample": float(r["stats"][0]) / samples,
+            "single_thread": {"value": width * len(rows) / dt1 / 1e6, "unit": "Msamples/s", "cores": 1,
+                              "sample": f"every 2nd row of the frame at 1 spp ({width * len(rows)} samples, {dt1:.1f} s)"}}
+
+
+class HostStaged:
+    """torch.distributed look-alike whose collectives stage device tensors through the host
+    (rehearsal mode only: gloo between ranks that share one GPU)."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def all_reduce(self, t, op):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def reduce(self, t, dst, op):
+        h = t.cpu()
+        self._d.reduce(h, dst=dst, op=op)
+        t.copy_(h)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
 
 
 def main():
@@ -78,10 +112,19 @@ def main():
     if world_size != args.gpus:
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 as: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        # Rehearsal of the N>1 flow on a box with ONE GPU: every rank uses device 0 and the
+        # collectives run over gloo on host copies.  The numbers mean nothing; the frame must.
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+            dist = HostStaged(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.scene == "final":
         cs, sph, mat = rt.build_final_scene(1, args.width)
@@ -169,6 +212,14 @@ def main():
                          "traffic": None, "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
                          "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
         }
+        if args.verify:
+            # the gathered frame against one single-GPU rt_render_region call over all total_spp samples
+            import numpy as np
+            frame = (image if (by_samples or world_size == 1) else gathered).cpu().numpy()
+            cs.samples_per_pixel = total_spp
+            whole = np.zeros((h, w, 3))
+            rt.render_region(whole, (0, 0, w, h), rt.calculate_camera_render_data(cs), sph, mat, seed=1, device=local_rank)
+            out["verified"] = bool(np.array_equal(frame, whole))
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(rt, cam, sph, mat, w, h, args.cpu_seconds)
         print(json.dumps(out), flush=True)
