@@ -25,6 +25,12 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for c, v in acc.items():
             allc[c] = sum(v) / len(v)
+traffic = {}
+for name in ("traffic_fetch", "traffic_write"):
+    for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
+        vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(f)) if "render_kernel" in row["Kernel_Name"]]
+        if vals:
+            traffic[name] = sum(vals) / len(vals)
 print("== PMC means per render_kernel dispatch (bench.py --steps 1 --warmup 0 --spp 100: 8.1e7 samples per dispatch)")
 for c in sorted(allc):
     print(f"   {c:28s} {allc[c]:.6g}")
@@ -35,10 +41,18 @@ if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
     if g("GRBM_GUI_ACTIVE"):
         cyc = g("GRBM_GUI_ACTIVE") / 8.0  # summed over the 8 XCDs
         print(f"   kernel cycles          = GRBM_GUI_ACTIVE / 8 = {cyc:.4g}")
-        print(f"   VALU issue occupancy   = 2 cycles * SQ_INSTS_VALU / 1024 SIMDs / kernel cycles = {2 * g('SQ_INSTS_VALU') / 1024 / cyc:.3f}")
-    if g("SQ_INSTS_VALU_FMA_F32"):
-        tests = g("SQ_INSTS_VALU_FMA_F32") / 6.0
-        print(f"   wave-level sphere tests = SQ_INSTS_VALU_FMA_F32 / 6 = {tests:.4g}; VALU instructions per test = {g('SQ_INSTS_VALU') / tests:.2f}; SALU per test = {g('SQ_INSTS_SALU', 0) / tests:.2f}")
-    if g("FETCH_SIZE") is not None or g("WRITE_SIZE") is not None:
-        print(f"   FETCH_SIZE = {g('FETCH_SIZE', float('nan')):.6g} KB, WRITE_SIZE = {g('WRITE_SIZE', float('nan')):.6g} KB per dispatch (rocprofv3 units: KB)")
+        if g("SQ_ACTIVE_INST_VALU"):
+            print(f"   VALUBusy               = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / kernel cycles = {100 * 4 * g('SQ_ACTIVE_INST_VALU') / 1024 / cyc:.1f} %")
+        if g("SQ_INSTS_VALU_FMA_F32"):
+            # fused multiply-adds are the packed ones of the scan (4 cycles per wave), the rest issue in 2
+            pk, rest = g("SQ_INSTS_VALU_FMA_F32"), g("SQ_INSTS_VALU") - g("SQ_INSTS_VALU_FMA_F32")
+            print(f"   VALU issue cycles      = (4 * FMA_F32 + 2 * other VALU) / 1024 SIMDs / kernel cycles = {(4 * pk + 2 * rest) / 1024 / cyc:.3f}")
+            print(f"   instruction mix        : FMA_F32 {pk / g('SQ_INSTS_VALU'):.3f} of VALU instructions; SALU per VALU {g('SQ_INSTS_SALU', 0) / g('SQ_INSTS_VALU'):.3f}")
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY") is not None:
+        print(f"   wave time              : issue-stalled {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}, parked on waitcnt {g('SQ_WAIT_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}, executing {g('SQ_ACTIVE_INST_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}")
+if traffic:
+    f, w = traffic.get("traffic_fetch", float("nan")), traffic.get("traffic_write", float("nan"))
+    print("== memory-side traffic of one 500-spp dispatch (4.05e8 samples; rocprofv3 reports KiB; FETCH_SIZE doubled as gfx950 tallies 128-B reads at 64 B)")
+    print(f"   FETCH_SIZE {f:.6g} KiB -> {2 * f * 1024 / 1e9:.4f} GB read;  WRITE_SIZE {w:.6g} KiB -> {w * 1024 / 1e9:.3f} GB written (8-byte integer atomics, width uncalibrated)")
+    allc["TRAFFIC_BYTES_500SPP"] = (2 * f + w) * 1024
 json.dump(allc, open(os.path.join(out, "counters.json"), "w"), indent=1)
