@@ -46,6 +46,19 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(args):
+    """HBM-side bytes of one render_kernel launch of the default workload, from the committed
+    rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile.sh writes
+    TRAFFIC_BYTES_500SPP into the counter summary); None for any other workload."""
+    if (args.scene, args.width, args.spp) != ("final", 1200, 500):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_counters.json")) as f:
+            return float(json.load(f)["TRAFFIC_BYTES_500SPP"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
     """The oracle (CPU restatement of the reference, f64, its literal operation order) on a
     bounded sample of the same workload: the full frame at the spp that fits the time budget."""
@@ -209,7 +222,7 @@ def main():
             "segments_per_sample": segments / max(1, samples_rank),
             "lane_utilization": segments / max(1, 64 * wave_iters),
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": None, "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
+                         "traffic": measured_traffic(args), "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
                          "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
         }
         if args.verify:
