@@ -215,6 +215,20 @@ int32_t rt_finalize(rt_world *world, const void *d_accum, int32_t precision,
                     int64_t strip_rows, int32_t strip_index, int32_t strip_count,
                     int64_t total_samples, rt_v3 *d_image, rt_v3 *d_linear, void *stream);
 
+/*
+ * The same tail followed by the body of serialize_ppm (main.odin:806-820) on
+ * the device, for the whole image: for the pixels of the selected strips,
+ * d_text + 12 * (u + v*width) receives the 12 bytes "RRR GGG BBB\n", each
+ * channel u8(256 * min(sqrt(mean), 0.999)) (main.odin:812-814) right-aligned
+ * in three columns.  d_text is a 4-byte-aligned device buffer of
+ * width*height*12 bytes; with the header "P3\n{w} {h}\n255\n" in front it is
+ * the file serialize_ppm produces from the image rt_finalize writes.
+ */
+int32_t rt_finalize_ppm(rt_world *world, const void *d_accum, int32_t precision,
+                        int64_t width, int64_t height,
+                        int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                        int64_t total_samples, char *d_text, void *stream);
+
 /* device time in ns of the render kernels launched for `world` by the last
  * rt_render_accumulate on it (blocks until they finish); <0 on error */
 int64_t rt_world_last_kernel_ns(rt_world *world);
@@ -261,6 +275,18 @@ int32_t rt_build_stress_scene(uint64_t seed, int64_t total_spheres, int64_t imag
  */
 int64_t rt_serialize_ppm(const rt_v3 *image_data, int64_t width, int64_t height,
                          char *dst, int64_t capacity);
+/*
+ * main (main.odin:840-848) from the render call to the serialised image in
+ * one step: rt_render_tiled followed by serialize_ppm, with the quantiser and
+ * the text formatting done on the GPU, so that 12 bytes per pixel cross PCIe
+ * instead of 24 and the host formats nothing.  Byte for byte the output of
+ * rt_serialize_ppm on the image rt_render_tiled returns.  Same size/capacity
+ * protocol as rt_serialize_ppm; a negative RT_ERR_* on failure.
+ */
+int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data *cam,
+                      const rt_sphere *spheres, int64_t n_spheres,
+                      const rt_material *materials, int64_t n_materials,
+                      const rt_options *opts, char *dst, int64_t capacity);
 /* the quantiser of main.odin:812-814 alone: rgb8 gets width*height*3 bytes */
 int32_t rt_quantize_rgb8(const rt_v3 *image_data, int64_t n_pixels, uint8_t *rgb8);
 

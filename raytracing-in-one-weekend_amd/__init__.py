@@ -133,6 +133,10 @@ def lib() -> C.CDLL:
     L.rt_render_accumulate.restype = i32
     L.rt_finalize.argtypes = [vp, vp, i32, i64, i64, Rect, i64, i32, i32, i64, vp, vp, vp]
     L.rt_finalize.restype = i32
+    L.rt_finalize_ppm.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, i64, vp, vp]
+    L.rt_finalize_ppm.restype = i32
+    L.rt_render_ppm.argtypes = [i64, i64, P(CameraRenderData), vp, i64, vp, i64, P(Options), vp, i64]
+    L.rt_render_ppm.restype = i64
     L.rt_world_last_kernel_ns.argtypes = [vp]
     L.rt_world_last_kernel_ns.restype = i64
     L.rt_lookat.argtypes = [V3, V3, V3, P(V3), P(V3), P(V3)]
@@ -161,7 +165,7 @@ EXPORTED_SYMBOLS = (
     "rt_version", "rt_last_error", "rt_device_count", "rt_options_default", "rt_render_region", "rt_render_tiled",
     "rt_world_create", "rt_world_destroy", "rt_render_accumulate", "rt_finalize", "rt_world_last_kernel_ns", "rt_lookat",
     "rt_calculate_camera_render_data", "rt_build_dev_scene", "rt_build_two_sphere_scene", "rt_build_final_scene",
-    "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32",
+    "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32", "rt_finalize_ppm", "rt_render_ppm",
 )
 
 
@@ -232,6 +236,26 @@ def serialize_ppm(image: np.ndarray) -> bytes:
     got = lib().rt_serialize_ppm(image.ctypes.data, w, h, buf, need)
     if got != need:
         raise RtError(int(got), "rt_serialize_ppm failed")
+    return buf.raw[:need]
+
+
+def render_ppm(width: int, height: int, camera_render_data: CameraRenderData, spheres: np.ndarray, materials: np.ndarray, *,
+               seed: int = 0, rng_mode: int = RNG_DETERMINISTIC, precision: int = PRECISION_F32, sphere_fetch: int = FETCH_AUTO,
+               device: int = -1, device_count: int = 1, sample_chunks: int = 0) -> bytes:
+    """render_tiled followed by serialize_ppm (main.odin:840-848) with the quantiser and the text
+    formatting on the GPU; the bytes equal serialize_ppm(render_tiled(...))."""
+    spheres, materials, sp, ns, mp, nm = _scene_ptrs(spheres, materials)
+    o = Options()
+    lib().rt_options_default(C.byref(o))
+    o.seed, o.rng_mode, o.precision, o.sphere_fetch = seed, rng_mode, precision, sphere_fetch
+    o.device, o.device_count, o.sample_chunks = device, device_count, sample_chunks
+    need = lib().rt_render_ppm(width, height, C.byref(camera_render_data), sp, ns, mp, nm, C.byref(o), None, 0)
+    if need < 0:
+        raise RtError(int(need), lib().rt_last_error().decode())
+    buf = C.create_string_buffer(int(need))
+    got = lib().rt_render_ppm(width, height, C.byref(camera_render_data), sp, ns, mp, nm, C.byref(o), buf, need)
+    if got != need:
+        raise RtError(int(got), lib().rt_last_error().decode())
     return buf.raw[:need]
 
 
@@ -320,6 +344,13 @@ class World:
         region = (0, 0, width, height) if region is None else region
         _check(lib().rt_finalize(self._h, d_accum, precision, width, height, Rect(*[int(v) for v in region]), strip_rows, strip_index,
                                  strip_count, total_samples, d_image, d_linear or None, stream or None))
+
+    def finalize_ppm(self, d_accum: int, width: int, height: int, total_samples: int, d_text: int, *, strip_rows: int = 8,
+                     strip_index: int = 0, strip_count: int = 1, precision: int = PRECISION_F32, stream: int = 0) -> None:
+        """the tail of the pixel loop and the body of serialize_ppm (main.odin:577-586, :806-820) on the device:
+        12 bytes of text per pixel at d_text + 12 * (u + v*width)"""
+        _check(lib().rt_finalize_ppm(self._h, d_accum, precision, width, height, strip_rows, strip_index, strip_count, total_samples,
+                                     d_text, stream or None))
 
     def last_kernel_ns(self) -> int:
         ns = lib().rt_world_last_kernel_ns(self._h)

@@ -404,12 +404,43 @@ int32_t rt_finalize(rt_world *world, const void *d_accum, int32_t precision, int
     return RT_OK;
 }
 
-int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_rect region, const rt_camera_render_data *cam,
-                         const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
-                         const rt_options *opts) {
+int32_t rt_finalize_ppm(rt_world *world, const void *d_accum, int32_t precision, int64_t width, int64_t height,
+                        int64_t strip_rows, int32_t strip_index, int32_t strip_count, int64_t total_samples,
+                        char *d_text, void *stream) {
+    if (world == nullptr || d_accum == nullptr || d_text == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, d_accum or d_text is NULL");
+    if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
+    if (total_samples <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "total_samples %lld <= 0", (long long)total_samples);
+    if ((reinterpret_cast<uintptr_t>(d_text) & 3u) != 0) return fail(RT_ERR_INVALID_ARGUMENT, "d_text must be 4-byte aligned");
+    Work wk;
+    const rt_rect whole = {0, 0, width, height};
+    int32_t rc = plan_work(width, height, whole, strip_rows, strip_index, strip_count, wk);
+    if (rc != RT_OK) return rc;
+    if (wk.map.n_tiles == 0) return RT_OK;
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(world->device));
+    rtk::PpmParams f{};
+    f.accum = d_accum;
+    f.text = reinterpret_cast<uint32_t *>(d_text);
+    f.total_samples = total_samples;
+    f.width = static_cast<int32_t>(width);
+    f.min_x = wk.min_x; f.min_y = wk.min_y; f.max_x = wk.max_x; f.max_y = wk.max_y; f.map = wk.map;
+    HIP_TRY(rtk::launch_finalize_ppm(f, precision, static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// rt_render_region and rt_render_ppm: host buffers in, host buffers out.  Exactly one of
+// image_data (f64 image of `region`) and ppm_body (12 bytes of text per pixel of the whole
+// image) is non-NULL.
+int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t height, rt_rect region, const rt_camera_render_data *cam,
+                       const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                       const rt_options *opts) {
     rt_options o;
     if (opts) o = *opts; else rt_options_default(&o);
-    if (image_data == nullptr || cam == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "image_data or cam is NULL");
+    if ((image_data == nullptr && ppm_body == nullptr) || cam == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer or cam is NULL");
     if (!precision_ok(o.precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", o.precision);
     if (o.rng_mode != RT_RNG_STOCHASTIC && o.rng_mode != RT_RNG_DETERMINISTIC) return fail(RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %d", o.rng_mode);
     // the reference divides by samples_per_pixel (main.odin:512); zero or negative counts have no meaningful image
@@ -436,7 +467,7 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
     }
 
     struct PerDevice {
-        int device = 0; rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr;
+        int device = 0; rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr; char *text = nullptr;
         uint64_t *stats = nullptr; hipStream_t stream = nullptr;
     };
     std::vector<PerDevice> devs(count);
@@ -449,6 +480,7 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
             if (d.stream) { (void)hipStreamSynchronize(d.stream); (void)hipStreamDestroy(d.stream); }
             if (d.accum) (void)hipFree(d.accum);
             if (d.image) (void)hipFree(d.image);
+            if (d.text) (void)hipFree(d.text);
             if (d.linear) (void)hipFree(d.linear);
             if (d.stats) (void)hipFree(d.stats);
             rt_world_destroy(d.world);
@@ -466,8 +498,9 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
         hipError_t e = hipSetDevice(d.device);
         if (e == hipSuccess) e = hipStreamCreate(&d.stream);
         if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * accum_size(o.precision));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.image), n_px * 3 * sizeof(double));
-        if (e == hipSuccess && o.linear_out) e = hipMalloc(reinterpret_cast<void **>(&d.linear), n_px * 3 * sizeof(double));
+        if (e == hipSuccess && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.image), n_px * 3 * sizeof(double));
+        if (e == hipSuccess && ppm_body) e = hipMalloc(reinterpret_cast<void **>(&d.text), n_px * 12);
+        if (e == hipSuccess && o.linear_out && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.linear), n_px * 3 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.stats), sizeof(uint64_t) * RT_STATS_COUNT);
         if (e == hipSuccess) e = hipMemsetAsync(d.stats, 0, sizeof(uint64_t) * RT_STATS_COUNT, d.stream);
         if (e != hipSuccess) { result = fail(RT_ERR_DEVICE, "device %d set-up failed: %s", d.device, hipGetErrorString(e)); break; }
@@ -476,8 +509,11 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
         result = rt_render_accumulate(d.world, cam, width, height, region, strip_rows, g, count, 0, cam->samples_per_pixel, seed, o.precision,
                                       o.sphere_fetch, o.sample_chunks, d.accum, d.stats, d.stream);
         if (result != RT_OK) break;
-        result = rt_finalize(d.world, d.accum, o.precision, width, height, region, strip_rows, g, count, cam->samples_per_pixel,
-                             reinterpret_cast<rt_v3 *>(d.image), reinterpret_cast<rt_v3 *>(d.linear), d.stream);
+        if (image_data)
+            result = rt_finalize(d.world, d.accum, o.precision, width, height, region, strip_rows, g, count, cam->samples_per_pixel,
+                                 reinterpret_cast<rt_v3 *>(d.image), reinterpret_cast<rt_v3 *>(d.linear), d.stream);
+        else
+            result = rt_finalize_ppm(d.world, d.accum, o.precision, width, height, strip_rows, g, count, cam->samples_per_pixel, d.text, d.stream);
     }
     // copy each device's strips of the region back: rows [y0, y1), columns of the region
     const size_t pitch = static_cast<size_t>(width) * sizeof(rt_v3);
@@ -489,6 +525,11 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
         for (int64_t y0 = region.min_y + g * strip_rows; e == hipSuccess && y0 < region.one_past_max_y; y0 += strip_rows * count) {
             const int64_t y1 = std::min<int64_t>(region.one_past_max_y, count == 1 ? region.one_past_max_y : y0 + strip_rows);
             const size_t off = static_cast<size_t>(y0) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x);
+            if (ppm_body) { // whole rows of text are contiguous
+                e = hipMemcpy(ppm_body + off * 12, d.text + off * 12, static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * 12, hipMemcpyDeviceToHost);
+                if (count == 1) break;
+                continue;
+            }
             e = hipMemcpy2D(image_data + off, pitch, reinterpret_cast<rt_v3 *>(d.image) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
             if (e == hipSuccess && o.linear_out)
                 e = hipMemcpy2D(o.linear_out + off, pitch, reinterpret_cast<rt_v3 *>(d.linear) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
@@ -513,6 +554,33 @@ int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_re
     (void)hipSetDevice(prev_device);
     if (result != RT_OK) g_error = keep;
     return result;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_rect region, const rt_camera_render_data *cam,
+                         const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                         const rt_options *opts) {
+    if (image_data == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "image_data is NULL");
+    return render_to_host(image_data, nullptr, width, height, region, cam, spheres, n_spheres, materials, n_materials, opts);
+}
+
+int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data *cam,
+                      const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                      const rt_options *opts, char *dst, int64_t capacity) {
+    if (width < 0 || height < 0) return fail(RT_ERR_INVALID_ARGUMENT, "negative image size");
+    char header[64];
+    const int header_len = std::snprintf(header, sizeof header, "P3\n%lld %lld\n255\n", (long long)width, (long long)height);
+    const int64_t need = header_len + width * height * 12;
+    if (dst == nullptr || capacity < need) return need;
+    if (opts && opts->linear_out) return fail(RT_ERR_INVALID_ARGUMENT, "linear_out is not available from rt_render_ppm");
+    std::memcpy(dst, header, static_cast<size_t>(header_len));
+    if (width * height == 0) return need;
+    const rt_rect whole = {0, 0, width, height};
+    const int32_t rc = render_to_host(nullptr, dst + header_len, width, height, whole, cam, spheres, n_spheres, materials, n_materials, opts);
+    return rc == RT_OK ? need : rc;
 }
 
 int32_t rt_render_tiled(rt_v3 *image_data, int64_t width, int64_t height, const rt_camera_render_data *cam,

@@ -85,4 +85,13 @@ struct FinalizeParams {
 };
 hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream);
 
+// The same tail followed by the body of serialize_ppm (main.odin:806-820): 12 bytes of text per
+// pixel, "RRR GGG BBB\n", written as three 32-bit words at text[3 * (u + v*width)].
+struct PpmParams {
+    const void *accum; uint32_t *text;
+    int64_t total_samples;
+    int32_t width; int32_t min_x, min_y, max_x, max_y; TileMap map;
+};
+hipError_t launch_finalize_ppm(const PpmParams &p, int arith, hipStream_t stream);
+
 } // namespace rtk

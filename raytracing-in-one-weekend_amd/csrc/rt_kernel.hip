@@ -30,6 +30,7 @@
 //   the F32_FMA scan.  Division and square root are IEEE correctly rounded.  Everything outside
 //   the scan follows the reference's operation order.
 #include "rt_kernel.h"
+#include <type_traits>
 
 #include <algorithm>
 
@@ -660,6 +661,37 @@ __global__ void finalize_q_kernel(const FinalizeParams P) {
     }
 }
 
+// serialize_ppm's body on the device (main.odin:806-820): each channel is
+// u8(256 * min(x, 0.999)) printed right-aligned in three columns and followed by ' ' (after blue:
+// '\n'), i.e. one little-endian 32-bit word per channel.  The gamma value x is formed exactly as
+// finalize_kernel / finalize_q_kernel form it, so the text equals that of the host writer run on
+// the f64 image.
+__device__ __forceinline__ uint32_t ppm_word(double x, bool last) {
+    const double clipped = (0.999 < x) ? 0.999 : x;
+    const uint32_t v = static_cast<uint32_t>(static_cast<uint8_t>(static_cast<long long>(256.0 * clipped)));
+    const uint32_t hundreds = v / 100u, tens = (v / 10u) % 10u, ones = v % 10u;
+    const uint32_t c0 = v >= 100u ? 0x30u + hundreds : 0x20u;
+    const uint32_t c1 = v >= 10u ? 0x30u + tens : 0x20u;
+    return c0 | (c1 << 8) | ((0x30u + ones) << 16) | ((last ? 0x0au : 0x20u) << 24);
+}
+template <int ARITH> __global__ void finalize_ppm_kernel(const PpmParams P) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    double g[3];
+    if constexpr (ARITH == ARITH_F32_FMA) {
+        const unsigned long long *in = static_cast<const unsigned long long *>(P.accum) + idx * 3;
+        const double contribution = 1.0 / static_cast<double>(P.total_samples);
+        for (int c = 0; c < 3; ++c) g[c] = sqrt_rn((q32_32_to_f64(in[c]) * (1.0 / 4294967296.0)) * contribution);
+    } else {
+        using Real = typename std::conditional<ARITH == ARITH_F64, double, float>::type;
+        const Real *in = static_cast<const Real *>(P.accum) + idx * 3;
+        const Real contribution = Real(1) / static_cast<Real>(P.total_samples);
+        for (int c = 0; c < 3; ++c) g[c] = static_cast<double>(sqrt_rn(in[c] * contribution));
+    }
+    uint32_t *out = P.text + idx * 3;
+    out[0] = ppm_word(g[0], false); out[1] = ppm_word(g[1], false); out[2] = ppm_word(g[2], true);
+}
+
 // ----------------------------------------------------------------------------- launchers
 template <class K> static void launch_k(K kernel, dim3 grid, int fetch, int n_records, size_t rec_bytes, hipStream_t stream, const RenderParams &p) {
     const size_t lds = fetch == FETCH_LDS ? static_cast<size_t>(n_records + GROUP) * rec_bytes : 0;
@@ -712,6 +744,14 @@ hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t strea
     if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_q_kernel, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(finalize_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_ppm(const PpmParams &p, int arith, hipStream_t stream) {
+    if (p.map.n_tiles <= 0) return hipSuccess;
+    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F64>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_FMA>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_LITERAL>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -274,3 +274,40 @@ def test_stochastic_mode_noise_band(rt, oracle):
     img, lin = np.zeros((h, w, 3)), np.zeros((h, w, 3))
     rt.render_region(img, (0, 0, w, h), cam4, sph, mat, seed=77, linear_out=lin)
     assert 0.4 < rmse(lin) / np.mean(gpu) < 0.62
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_device_ppm_equals_host_serialize_ppm(rt, oracle, precision):
+    """rt_render_ppm (quantiser and text formatting on the GPU) against serialize_ppm of the
+    rendered f64 image: the host mirror's and the oracle's writer (main.odin:791-824)."""
+    cs, cam, sph, mat = scene(rt, "dev", 75, 5)   # 75x42: a ragged last tile column and row
+    w, h = cs.image_width, cs.image_height
+    image, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=9, precision=precision)
+    text = rt.render_ppm(w, h, cam, sph, mat, seed=9, precision=precision)
+    assert text == rt.serialize_ppm(image)
+    assert text == oracle.serialize_ppm(image)
+    assert text.startswith(b"P3\n75 42\n255\n") and len(text) == len(b"P3\n75 42\n255\n") + 12 * w * h
+
+
+def test_device_ppm_strips_and_extremes(rt):
+    """rt_finalize_ppm on strips of a device-resident accumulator, with channel values that hit
+    every column width: 0, 9, 10, 99, 100, 255 (x >= 0.999 clips to 255)."""
+    import torch
+    w, h, spp = 24, 20, 4
+    cs, cam, sph, mat = scene(rt, "two", w, spp)
+    world = rt.World(sph, mat)
+    dev = torch.device("cuda:0")
+    gamma = np.array([0.0, 0.036, 0.04, 0.3898, 0.391, 0.9985, 0.9991, 1.0, 1.7])
+    lin = np.resize(gamma ** 2, (cs.image_height, w, 3))
+    q = np.floor(lin * spp * 2.0 ** 32).astype(np.int64)            # Q32.32 sums of spp samples
+    accum = torch.from_numpy(q).to(dev)
+    text = torch.zeros(cs.image_height * w * 12, dtype=torch.uint8, device=dev)
+    for r in range(2):
+        world.finalize_ppm(accum.data_ptr(), w, cs.image_height, spp, text.data_ptr(), strip_rows=8, strip_index=r, strip_count=2)
+    img = torch.zeros(cs.image_height, w, 3, dtype=torch.float64, device=dev)
+    world.finalize(accum.data_ptr(), w, cs.image_height, spp, img.data_ptr())
+    torch.cuda.synchronize()
+    body = rt.serialize_ppm(img.cpu().numpy()).split(b"255\n", 1)[1]
+    assert bytes(text.cpu().numpy()) == body
+    assert b"  0 " in body and b"255" in body and b" 99 " in body and b"100 " in body
+    world.close()

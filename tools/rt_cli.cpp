@@ -2,7 +2,9 @@
 // through the C ABI -- build a scene, compute the camera, render, print a P3 PPM to stdout --
 // with the scene, size, sample count and seed selectable at run time.
 //   rt_cli [--scene dev|two|final|stress] [--width W] [--spp N] [--depth D] [--seed S]
-//          [--gpus G] [--precision f32|f64|f32-literal] [--stochastic] [--stats] > out.ppm
+//          [--gpus G] [--precision f32|f64|f32-literal] [--stochastic] [--stats] [--host-ppm] > out.ppm
+// The PPM text is formatted on the GPU (rt_render_ppm); --host-ppm takes the reference's route
+// instead: the f64 image comes back and rt_serialize_ppm formats it on the host.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +19,7 @@ int main(int argc, char **argv) {
     int64_t width = 0, spp = 0, depth = -1;
     uint64_t seed = 1;
     int gpus = 1;
-    bool stochastic = false, want_stats = false;
+    bool stochastic = false, want_stats = false, host_ppm = false;
     for (int i = 1; i < argc; ++i) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--scene")) scene = next();
@@ -29,6 +31,7 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--precision")) precision = next();
         else if (!std::strcmp(argv[i], "--stochastic")) stochastic = true;
         else if (!std::strcmp(argv[i], "--stats")) want_stats = true;
+        else if (!std::strcmp(argv[i], "--host-ppm")) host_ppm = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     rt_camera_settings settings;
@@ -46,7 +49,6 @@ int main(int argc, char **argv) {
     if (depth >= 0) settings.max_ray_bounces = depth;
 
     const int64_t w = static_cast<int64_t>(settings.image_size_x), h = static_cast<int64_t>(settings.image_size_y);
-    std::vector<rt_v3> image(static_cast<size_t>(w * h));
     rt_camera_render_data cam;
     rt_calculate_camera_render_data(&settings, &cam);
 
@@ -61,18 +63,24 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "%s: %s scene, %lld spheres, %lldx%lld, %lld spp, depth %lld, %d GPU(s)\n", rt_version(), scene.c_str(), (long long)ns,
                  (long long)w, (long long)h, (long long)settings.samples_per_pixel, (long long)settings.max_ray_bounces, gpus);
     const auto t0 = std::chrono::steady_clock::now();
-    rc = rt_render_tiled(image.data(), w, h, &cam, spheres.data(), ns, materials.data(), nm, &opts);
+    const int64_t need = rt_serialize_ppm(nullptr, w, h, nullptr, 0);
+    std::vector<char> ppm(static_cast<size_t>(need));
+    if (host_ppm) {
+        std::vector<rt_v3> image(static_cast<size_t>(w * h));
+        rc = rt_render_tiled(image.data(), w, h, &cam, spheres.data(), ns, materials.data(), nm, &opts);
+        if (rc != RT_OK) { std::fprintf(stderr, "rt_render_tiled failed (%d): %s\n", rc, rt_last_error()); return 1; }
+        rt_serialize_ppm(image.data(), w, h, ppm.data(), need);
+    } else {
+        const int64_t got = rt_render_ppm(w, h, &cam, spheres.data(), ns, materials.data(), nm, &opts, ppm.data(), need);
+        if (got != need) { std::fprintf(stderr, "rt_render_ppm failed (%lld): %s\n", (long long)got, rt_last_error()); return 1; }
+    }
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rc != RT_OK) { std::fprintf(stderr, "rt_render_tiled failed (%d): %s\n", rc, rt_last_error()); return 1; }
     if (want_stats)
-        std::fprintf(stderr, "Done. %.3f s wall (%.1f Msamples/s incl. copies), kernel %.3f ms, %.3f segments/sample, %llu sphere tests\n", seconds,
+        std::fprintf(stderr, "Done. %.3f s wall to the serialised image (%.1f Msamples/s incl. set-up, copies and PPM text), kernel %.3f ms, %.3f segments/sample, %llu sphere tests\n", seconds,
                      w * h * settings.samples_per_pixel / seconds / 1e6, stats[RT_STAT_KERNEL_NS] / 1e6,
                      double(stats[RT_STAT_SEGMENTS]) / double(stats[RT_STAT_SAMPLES]), (unsigned long long)stats[RT_STAT_SPHERE_TESTS]);
     else
         std::fprintf(stderr, "Done.\n");
-    const int64_t need = rt_serialize_ppm(image.data(), w, h, nullptr, 0);
-    std::vector<char> ppm(static_cast<size_t>(need));
-    rt_serialize_ppm(image.data(), w, h, ppm.data(), need);
     std::fwrite(ppm.data(), 1, ppm.size(), stdout);
     return 0;
 }
