@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--scene", default="final", choices=["final", "dev", "stress"])
     ap.add_argument("--partition", default="samples", choices=["samples", "rows"])
-    ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds"])
+    ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds", "bvh"],
+                    help="bvh: closest hit through the bounding-volume hierarchy (not the headline: the roofline then counts the tests carried out)")
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="after timing, rank 0 re-renders the frame in one rt_render_region call and compares bitwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +149,7 @@ def main():
     cs.samples_per_pixel = args.spp
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
-    fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS}[args.fetch]
+    fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS, "bvh": rt.FETCH_BVH}[args.fetch]
 
     world = rt.World(sph, mat, device=local_rank)
     accum = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums: exact, so the all-reduce is order-independent
@@ -184,6 +185,7 @@ def main():
     segments = int(stats[rt.STAT_SEGMENTS].item())
     samples_rank = int(stats[rt.STAT_SAMPLES].item())
     wave_iters = int(stats[rt.STAT_WAVE_ITERATIONS].item())
+    bvh_nodes, bvh_tests = int(stats[rt.STAT_BVH_NODES].item()), int(stats[rt.STAT_BVH_TESTS].item())
     for _ in range(args.warmup):
         step()
     fence()
@@ -208,7 +210,8 @@ def main():
     value = samples_step * args.steps / elapsed / 1e6
 
     if rank == 0:
-        tests_rank = segments * len(sph)
+        # list scan: every segment tests every sphere; hierarchy: the tests the traversal carried out (counted by the kernel)
+        tests_rank = bvh_tests if args.fetch == "bvh" else segments * len(sph)
         achieved = F_TEST * tests_rank / kernel_s / 1e12
         out = {
             "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak",
@@ -222,9 +225,12 @@ def main():
             "segments_per_sample": segments / max(1, samples_rank),
             "lane_utilization": segments / max(1, 64 * wave_iters),
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic(args), "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
+                         "traffic": measured_traffic(args) if args.fetch != "bvh" else None,
+                         "kernel": "render_kernel<float, fma, bvh>" if args.fetch == "bvh" else "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
                          "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
         }
+        if args.fetch == "bvh":
+            out["bvh"] = {"boxes_per_segment": bvh_nodes / max(1, segments), "sphere_tests_per_segment": bvh_tests / max(1, segments)}
         if args.verify:
             # the gathered frame against one single-GPU rt_render_region call over all total_spp samples
             import numpy as np

@@ -87,10 +87,13 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 #define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
 #define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
 
-/* how a wave obtains the (wave-uniform) sphere records in the closest-hit scan */
-#define RT_FETCH_AUTO 0
-#define RT_FETCH_SCALAR 1 /* scalar-cache loads into SGPRs                              */
-#define RT_FETCH_LDS 2    /* SoA records staged once per workgroup into LDS, broadcast  */
+/* how the closest hit (main.odin:536-546) is found */
+#define RT_FETCH_AUTO 0   /* = RT_FETCH_SCALAR                                                     */
+#define RT_FETCH_SCALAR 1 /* list scan, records through scalar-cache loads into SGPRs              */
+#define RT_FETCH_LDS 2    /* list scan, SoA records staged once per workgroup into LDS, broadcast  */
+#define RT_FETCH_BVH 3    /* bounding-volume hierarchy over the spheres instead of the list (the
+                             TODO at main.odin:559); RT_PRECISION_F32 only; the image is the list
+                             scan's bit for bit, RT_STAT_SPHERE_TESTS counts the tests carried out  */
 
 #define RT_RNG_STOCHASTIC 0    /* seed is mixed with a per-process call counter and the clock */
 #define RT_RNG_DETERMINISTIC 1 /* the counter RNG is keyed by `seed` alone: same inputs, same image */
@@ -102,6 +105,8 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 #define RT_STAT_SAMPLES 3      /* camera rays started                                                       */
 #define RT_STAT_WAVE_ITERATIONS 4 /* sum over wave64s of their segment-loop trip count: segments / (64 * this)
                                   is the share of lanes that had a live ray in the closest-hit scan         */
+#define RT_STAT_BVH_NODES 5    /* RT_FETCH_BVH: bounding boxes tested, summed over lanes                    */
+#define RT_STAT_BVH_TESTS 6    /* RT_FETCH_BVH: ray/sphere tests carried out, summed over lanes             */
 #define RT_STATS_COUNT 8
 
 typedef struct {
@@ -289,6 +294,15 @@ int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data
                       const rt_options *opts, char *dst, int64_t capacity);
 /* the quantiser of main.odin:812-814 alone: rgb8 gets width*height*3 bytes */
 int32_t rt_quantize_rgb8(const rt_v3 *image_data, int64_t n_pixels, uint8_t *rgb8);
+
+/*
+ * Builds the hierarchy RT_FETCH_BVH traverses (host only, no GPU needed) and checks its
+ * invariants for all eight traversal orders: every sphere in exactly one leaf and strictly
+ * inside that leaf's box, every box inside its ancestors', skip links forward and leaves of at
+ * most 4 spheres in list order.  No counterpart in the reference (its closest-hit loop is the
+ * list, main.odin:536-546; the hierarchy is the TODO at :559).  n_nodes / max_leaf may be NULL.
+ */
+int32_t rt_bvh_validate(const rt_sphere *spheres, int64_t n_spheres, int64_t *n_nodes, int64_t *max_leaf);
 
 /* the counter RNG the kernels use: u32 draw for (seed, pixel, sample, bounce, draw) */
 uint32_t rt_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t draw);

@@ -27,9 +27,9 @@ RT_ERR_UNSUPPORTED = -4
 RT_ERR_BUFFER_TOO_SMALL = -5
 LAMBERTIAN, METALLIC, DIELECTRIC = 0, 1, 2
 PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL = 0, 1, 2
-FETCH_AUTO, FETCH_SCALAR, FETCH_LDS = 0, 1, 2
+FETCH_AUTO, FETCH_SCALAR, FETCH_LDS, FETCH_BVH = 0, 1, 2, 3
 RNG_STOCHASTIC, RNG_DETERMINISTIC = 0, 1
-STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES, STAT_WAVE_ITERATIONS = 0, 1, 2, 3, 4
+STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES, STAT_WAVE_ITERATIONS, STAT_BVH_NODES, STAT_BVH_TESTS = 0, 1, 2, 3, 4, 5, 6
 STATS_COUNT = 8
 
 # numpy views of the 40-byte Odin structs (main.odin:487-491, :285-289)
@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
     L.rt_finalize_ppm.restype = i32
     L.rt_render_ppm.argtypes = [i64, i64, P(CameraRenderData), vp, i64, vp, i64, P(Options), vp, i64]
     L.rt_render_ppm.restype = i64
+    L.rt_bvh_validate.argtypes = [vp, i64, P(i64), P(i64)]
+    L.rt_bvh_validate.restype = i32
     L.rt_world_last_kernel_ns.argtypes = [vp]
     L.rt_world_last_kernel_ns.restype = i64
     L.rt_lookat.argtypes = [V3, V3, V3, P(V3), P(V3), P(V3)]
@@ -165,7 +167,7 @@ EXPORTED_SYMBOLS = (
     "rt_version", "rt_last_error", "rt_device_count", "rt_options_default", "rt_render_region", "rt_render_tiled",
     "rt_world_create", "rt_world_destroy", "rt_render_accumulate", "rt_finalize", "rt_world_last_kernel_ns", "rt_lookat",
     "rt_calculate_camera_render_data", "rt_build_dev_scene", "rt_build_two_sphere_scene", "rt_build_final_scene",
-    "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32", "rt_finalize_ppm", "rt_render_ppm",
+    "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32", "rt_finalize_ppm", "rt_render_ppm", "rt_bvh_validate",
 )
 
 
@@ -257,6 +259,14 @@ def render_ppm(width: int, height: int, camera_render_data: CameraRenderData, sp
     if got != need:
         raise RtError(int(got), lib().rt_last_error().decode())
     return buf.raw[:need]
+
+
+def bvh_validate(spheres: np.ndarray):
+    """build the hierarchy of FETCH_BVH on the host and check its invariants; returns (n_nodes, max_leaf)"""
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    n_nodes, max_leaf = C.c_int64(0), C.c_int64(0)
+    _check(lib().rt_bvh_validate(spheres.ctypes.data, len(spheres), C.byref(n_nodes), C.byref(max_leaf)))
+    return int(n_nodes.value), int(max_leaf.value)
 
 
 def quantize_rgb8(image: np.ndarray) -> np.ndarray:

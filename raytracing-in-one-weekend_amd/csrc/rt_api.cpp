@@ -2,6 +2,7 @@
 // launch bookkeeping and the host <-> device copies of the one-shot entry points.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -13,6 +14,7 @@
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
+#include "rt_bvh.h"
 #include "rt_kernel.h"
 
 namespace {
@@ -86,6 +88,11 @@ struct rt_world_s {
     int32_t *sphere_material = nullptr;
     void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
     int32_t *material_type = nullptr;
+    // RT_FETCH_BVH: built and uploaded on first use from the host copies kept here
+    std::vector<float> h_rec32, h_k, h_rad32, h_rad32inv;
+    std::vector<int32_t> h_material;
+    void *bvh_nodes = nullptr, *bvh_spheres = nullptr;
+    int32_t bvh_n_nodes = 0;
     void *slabs = nullptr;                      // partial sums of sample chunks 1..
     size_t slab_bytes = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -238,6 +245,10 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         mtype[i] = static_cast<int32_t>(m.type);
     }
     rt_world *w = new rt_world_s();
+    w->h_rec32.assign(rec32.begin(), rec32.begin() + 4 * ns);
+    w->h_k.resize(ns);
+    for (size_t i = 0; i < ns; ++i) w->h_k[i] = rec32k[pair_slot(i, 3)];
+    w->h_rad32 = rad32; w->h_rad32inv = rad32inv; w->h_material = smat;
     w->device = current;
     w->n_spheres = static_cast<int32_t>(n_spheres);
     w->n_padded = static_cast<int32_t>(ns_pad);
@@ -281,7 +292,7 @@ int32_t rt_world_destroy(rt_world *w) {
     if (w == nullptr) return RT_OK;
     DeviceGuard guard;
     (void)guard.enter(w->device);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue};
+    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue, w->bvh_nodes, w->bvh_spheres};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
@@ -295,7 +306,8 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
                              int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
     if (world == nullptr || cam == nullptr || d_accum == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, cam or d_accum is NULL");
     if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
-    if (sphere_fetch != RT_FETCH_AUTO && sphere_fetch != RT_FETCH_SCALAR && sphere_fetch != RT_FETCH_LDS) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
+    if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
+    if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32) return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32 only");
     if (sample_begin < 0 || sample_count < 0 || sample_begin + sample_count > (int64_t(1) << 32) - 2) return fail(RT_ERR_INVALID_ARGUMENT, "samples [%lld, +%lld) outside [0, 2^32-2)", (long long)sample_begin, (long long)sample_count);
     if (cam->max_ray_bounces < 0 || cam->max_ray_bounces > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "max_ray_bounces %lld outside [0, 2^20]", (long long)cam->max_ray_bounces);
     if (sample_chunks < 0) return fail(RT_ERR_INVALID_ARGUMENT, "sample_chunks %d < 0", sample_chunks);
@@ -331,7 +343,18 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         }
     }
 
+    if (fetch == RT_FETCH_BVH && world->bvh_nodes == nullptr && world->n_spheres > 0) {
+        rtk::BvhHost bvh;
+        rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
+        HIP_TRY(hipMalloc(&world->bvh_nodes, bvh.nodes.size() * sizeof(rtk::BvhNode)));
+        HIP_TRY(hipMalloc(&world->bvh_spheres, bvh.spheres.size() * sizeof(rtk::BvhSphere)));
+        HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
+        world->bvh_n_nodes = bvh.n_nodes;
+    }
+
     rtk::RenderParams p{};
+    p.bvh_nodes = world->bvh_nodes; p.bvh_spheres = world->bvh_spheres; p.bvh_n_nodes = world->bvh_n_nodes;
     p.sphere_rec = f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32);
     p.sphere_center = f64 ? world->rec64 : world->rec32;
     p.sphere_radius = f64 ? world->rad64 : (precision == RT_PRECISION_F32 ? world->rad32inv : world->rad32);
@@ -542,13 +565,16 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
                 o.stats[RT_STAT_SEGMENTS] += h[RT_STAT_SEGMENTS];
                 o.stats[RT_STAT_SAMPLES] += h[RT_STAT_SAMPLES];
                 o.stats[RT_STAT_WAVE_ITERATIONS] += h[RT_STAT_WAVE_ITERATIONS];
+                o.stats[RT_STAT_BVH_NODES] += h[RT_STAT_BVH_NODES];
+                o.stats[RT_STAT_BVH_TESTS] += h[RT_STAT_BVH_TESTS];
                 const int64_t ns = rt_world_last_kernel_ns(d.world);
                 if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
             }
         }
         if (e != hipSuccess) result = fail(RT_ERR_DEVICE, "collecting from device %d failed: %s", d.device, hipGetErrorString(e));
     }
-    if (result == RT_OK && o.stats) o.stats[RT_STAT_SPHERE_TESTS] = o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
+    if (result == RT_OK && o.stats)
+        o.stats[RT_STAT_SPHERE_TESTS] = o.sphere_fetch == RT_FETCH_BVH ? o.stats[RT_STAT_BVH_TESTS] : o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
     const std::string keep = g_error;
     cleanup();
     (void)hipSetDevice(prev_device);
@@ -581,6 +607,54 @@ int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data
     const rt_rect whole = {0, 0, width, height};
     const int32_t rc = render_to_host(nullptr, dst + header_len, width, height, whole, cam, spheres, n_spheres, materials, n_materials, opts);
     return rc == RT_OK ? need : rc;
+}
+
+int32_t rt_bvh_validate(const rt_sphere *spheres, int64_t n_spheres, int64_t *n_nodes, int64_t *max_leaf) {
+    if (n_spheres < 0 || (n_spheres > 0 && spheres == nullptr)) return fail(RT_ERR_INVALID_ARGUMENT, "spheres is NULL or the count negative");
+    if (n_spheres > (1 << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 spheres");
+    const size_t ns = static_cast<size_t>(n_spheres);
+    std::vector<float> rec(4 * ns), k(ns), rad(ns), inv(ns);
+    std::vector<int32_t> mat(ns, 0);
+    for (size_t i = 0; i < ns; ++i) {
+        const float r = static_cast<float>(spheres[i].radius);
+        rec[4 * i] = static_cast<float>(spheres[i].center.x); rec[4 * i + 1] = static_cast<float>(spheres[i].center.y);
+        rec[4 * i + 2] = static_cast<float>(spheres[i].center.z); rec[4 * i + 3] = r * r;
+        rad[i] = r; inv[i] = 1.0f / r; k[i] = 0.0f;
+    }
+    rtk::BvhHost bvh;
+    rtk::build_bvh(rec.data(), k.data(), rad.data(), inv.data(), mat.data(), static_cast<int32_t>(n_spheres), bvh);
+    int64_t worst = 0;
+    std::vector<int> seen(ns, 0);
+    for (int oct = 0; oct < 8; ++oct) {
+        const rtk::BvhNode *nodes = bvh.nodes.data() + static_cast<size_t>(oct) * bvh.n_nodes;
+        std::fill(seen.begin(), seen.end(), 0);
+        // every node: skip link ahead and inside the array; boxes of a subtree inside the root of that subtree
+        for (int32_t i = 0; i < bvh.n_nodes; ++i) {
+            const rtk::BvhNode &nd = nodes[i];
+            if (nd.skip <= i || nd.skip > bvh.n_nodes) return fail(RT_ERR_DEVICE, "octant %d node %d: skip link %d", oct, i, nd.skip);
+            for (int32_t j = i + 1; j < nd.skip; ++j)
+                for (int a = 0; a < 3; ++a)
+                    if (nodes[j].bmin[a] < nd.bmin[a] || nodes[j].bmax[a] > nd.bmax[a]) return fail(RT_ERR_DEVICE, "octant %d node %d is not inside its ancestor %d", oct, j, i);
+            if (nd.leaf < 0) { if (nd.skip == i + 1) return fail(RT_ERR_DEVICE, "octant %d inner node %d has no subtree", oct, i); continue; }
+            if (nd.skip != i + 1) return fail(RT_ERR_DEVICE, "octant %d leaf %d has a subtree", oct, i);
+            const int first = nd.leaf >> 3, count = nd.leaf & 7;
+            if (count < 1 || count > rtk::BVH_LEAF_MAX || first + count > static_cast<int>(ns)) return fail(RT_ERR_DEVICE, "octant %d leaf %d: range [%d, +%d)", oct, i, first, count);
+            worst = std::max<int64_t>(worst, count);
+            for (int j = first; j < first + count; ++j) {
+                const rtk::BvhSphere &sp = bvh.spheres[j];
+                if (sp.index < 0 || sp.index >= static_cast<int>(ns) || seen[sp.index]++) return fail(RT_ERR_DEVICE, "octant %d: sphere %d appears twice or is out of range", oct, sp.index);
+                if (j > first && bvh.spheres[j - 1].index >= sp.index) return fail(RT_ERR_DEVICE, "octant %d leaf %d is not in list order", oct, i);
+                const float r = std::fabs(rad[sp.index]);
+                const float c[3] = {rec[4 * sp.index], rec[4 * sp.index + 1], rec[4 * sp.index + 2]};
+                for (int a = 0; a < 3; ++a)
+                    if (!(nd.bmin[a] < c[a] - r && c[a] + r < nd.bmax[a])) return fail(RT_ERR_DEVICE, "octant %d leaf %d does not contain sphere %d", oct, i, sp.index);
+            }
+        }
+        for (size_t i = 0; i < ns; ++i) if (seen[i] != 1) return fail(RT_ERR_DEVICE, "octant %d: sphere %zu is in %d leaves", oct, i, seen[i]);
+    }
+    if (n_nodes) *n_nodes = bvh.n_nodes;
+    if (max_leaf) *max_leaf = worst;
+    return RT_OK;
 }
 
 int32_t rt_render_tiled(rt_v3 *image_data, int64_t width, int64_t height, const rt_camera_render_data *cam,

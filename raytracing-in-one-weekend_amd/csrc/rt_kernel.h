@@ -19,7 +19,7 @@ constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 record
 // ARITH_F32_LITERAL: f32, reference operation order, accumulators are float
 enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2 };
 inline size_t accum_element_size(int arith) { return arith == ARITH_F32_LITERAL ? 4 : 8; }
-enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2 };
+enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2, FETCH_BVH = 3 };
 
 // camera_render_data (main.odin:440-448) as 19 numbers in the kernel's arithmetic type:
 // position, pixel_delta_u, pixel_delta_v, view_plane_top_left_pixel_center, dof_disk_u,
@@ -47,6 +47,10 @@ struct RenderParams {
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
     const int32_t *material_type;
     int32_t n_spheres;          // padded to a multiple of SCAN_STEP (pad records have r*r = -inf); GROUP more follow
+    // FETCH_BVH: the hierarchy (rt_bvh.h): 8 octant orders of bvh_n_nodes nodes (two float4 each), leaf spheres (two float4 each)
+    const void *bvh_nodes;
+    const void *bvh_spheres;
+    int32_t bvh_n_nodes;
     // image and work
     int32_t width, height;
     int32_t min_x, min_y, max_x, max_y; // region, half open

@@ -55,6 +55,7 @@ __device__ __forceinline__ double fma_rn(double a, double b, double c) { return 
 // IEEE maxNum: a NaN operand is ignored (v_max_f32 / v_max_f64)
 __device__ __forceinline__ float max_num(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double max_num(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float min_num(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float abs_rn(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_rn(double x) { return __builtin_fabs(x); }
 template <typename Real> __device__ __forceinline__ Real min_std(Real a, Real b) { return (b < a) ? b : a; } // std::min
@@ -163,8 +164,9 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
 
-template <typename Real, bool FMA, int FETCH, bool QUEUE>
+template <typename Real, bool FMA, int FETCH, bool QUEUE, bool BVH = false>
 __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
+    static_assert(!BVH || (FMA && QUEUE), "the hierarchy is traversed in the throughput arithmetic only");
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of SCAN_STEP
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
     int start_sphere = -1;
     V3<Real> start_center = {Real(0), Real(0), Real(0)};
     uint32_t segments = 0, started = 0;
+    uint32_t bvh_nodes = 0, bvh_tests = 0; // hierarchy mode: boxes and spheres this lane tested
 #ifdef RT_DIAG_COUNTERS
     // diagnostic build: how often the scan leaves its straight-line code
     uint32_t diag_entries = 0, diag_resolves = 0, diag_parked = 0;
@@ -412,6 +415,63 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
             const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
+            if constexpr (BVH) {
+                // Closest hit through the bounding-volume hierarchy instead of the list (the TODO at
+                // main.odin:559).  Per lane, no stack: nodes are in depth-first order for this ray's
+                // direction octant; a node whose box the segment [0, closest] meets is followed by
+                // the next node (its near child), any other by its skip link.  A leaf's spheres go
+                // through exactly the two stages of the list scan (same operations, same order), and
+                // among equal roots the lowest list index wins as in the list's strict `<`
+                // (main.odin:542), so the result is the list scan's bit for bit: the boxes are padded
+                // well beyond the rounding of the root evaluation, hence every sphere that
+                // evaluation reports as hit is reached.
+                const float4 *__restrict__ nodes = static_cast<const float4 *>(P.bvh_nodes) +
+                    static_cast<size_t>((rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0)) * static_cast<size_t>(P.bvh_n_nodes) * 2;
+                const float4 *__restrict__ leaves = static_cast<const float4 *>(P.bvh_spheres);
+                const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
+                int node = 0;
+                while (node < P.bvh_n_nodes) {
+                    const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
+                    ++bvh_nodes;
+                    // slab test; a NaN (0 * inf: origin on a slab plane of an axis the ray does not move along) is ignored by min/max
+                    const float tx0 = (lo.x - ro.x) * ix, tx1 = (hi.x - ro.x) * ix;
+                    const float ty0 = (lo.y - ro.y) * iy, ty1 = (hi.y - ro.y) * iy;
+                    const float tz0 = (lo.z - ro.z) * iz, tz1 = (hi.z - ro.z) * iz;
+                    const float t_in = max_num(max_num(min_num(tx0, tx1), min_num(ty0, ty1)), max_num(min_num(tz0, tz1), 0.0f));
+                    const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), closest));
+                    if (t_in <= t_out) {
+                        const int leaf = __float_as_int(hi.w);
+                        if (leaf >= 0) {
+                            const int first = leaf >> 3, count = leaf & 7;
+                            for (int j = first; j < first + count; ++j) {
+                                const float4 s0 = leaves[2 * j], s1 = leaves[2 * j + 1]; // {centre, K} {r*r, 1/r, index, material}
+                                const int index = __float_as_int(s1.z);
+                                ++bvh_tests;
+                                // stage 1: the list scan's filter
+                                const float h = fma_rn(s0.z, rd.z, fma_rn(s0.y, rd.y, fma_rn(s0.x, rd.x, -d_o)));
+                                const float m = fma_rn(s0.w, a, fma_rn(s0.z, aoz, fma_rn(s0.y, aoy, fma_rn(s0.x, aox, aoo))));
+                                const float disc = fma_rn(h, h, -m);
+                                if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) continue;
+                                // stage 2: the roots of `resolve`
+                                const float ocx = s0.x - ro.x, ocy = s0.y - ro.y, ocz = s0.z - ro.z;
+                                const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a;
+                                const float lx = fma_rn(-q, rd.x, ocx), ly = fma_rn(-q, rd.y, ocy), lz = fma_rn(-q, rd.z, ocz);
+                                const float D = s1.x - fma_rn(lz, lz, fma_rn(ly, ly, lx * lx));
+                                if (!(D >= 0.0f)) continue;
+                                const float sq = sqrt_rn(D * inv_a);
+                                float root = q - sq;
+                                if (root < t_min) root = q + sq; // the near root is behind t_min: the far one (main.odin:253-257)
+                                if (root < t_min) continue;
+                                // in list order the first sphere of the smallest root wins; the start sphere was tested before the list
+                                if (root < closest || (root == closest && hit != start_sphere && index < hit)) { closest = root; hit = index; }
+                            }
+                        }
+                        node = node + 1;
+                    } else {
+                        node = __float_as_int(lo.w);
+                    }
+                }
+            } else {
             const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
             const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {a, a};
             auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
@@ -440,6 +500,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 a0 = pair(i / 2 + 4); a1 = pair(i / 2 + 5);
                 test_pairs(b0, b1, i + 4);
             }
+            } // list scan
         } else {
             // literal modes: records are {centre, r*r}, the reference's expressions (main.odin:245-249)
             auto discriminant = [&](const R4 sp, Real &h, Real &cc) -> Real {
@@ -579,6 +640,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             atomicAdd(&P.stats[3], static_cast<unsigned long long>(smp));
             atomicAdd(&P.stats[4], static_cast<unsigned long long>(iters));
         }
+        if constexpr (BVH) {
+            uint32_t nb = bvh_nodes, nt = bvh_tests;
+            for (int off = 32; off > 0; off >>= 1) { nb += __shfl_xor(nb, off, 64); nt += __shfl_xor(nt, off, 64); }
+            if (lane == 0) {
+                atomicAdd(&P.stats[5], static_cast<unsigned long long>(nb));
+                atomicAdd(&P.stats[6], static_cast<unsigned long long>(nt));
+            }
+        }
 #ifdef RT_DIAG_COUNTERS
         // entries: per wave (uniform, take lane 0's); resolves: wave-level calls (max over lanes approximates); parked: lane total
         uint32_t par = diag_parked, res = diag_resolves;
@@ -707,7 +776,8 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
         // queue mode: as many workgroups as the chip holds at once (or fewer if the work is smaller)
         const int64_t waves_needed = static_cast<int64_t>(p.n_items);
         const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (waves_needed + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
-        if (lds) launch_k(render_kernel<float, true, FETCH_LDS, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
+        if (fetch == FETCH_BVH) launch_k(render_kernel<float, true, FETCH_SCALAR, true, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        else if (lds) launch_k(render_kernel<float, true, FETCH_LDS, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
         else launch_k(render_kernel<float, true, FETCH_SCALAR, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
         break;
     }

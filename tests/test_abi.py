@@ -129,3 +129,19 @@ def test_ppm_writer_matches_the_oracle(rt, oracle):
     assert lines[3] == b"  0 255 255" and lines[4] == b" 10   0 128"
     assert np.array_equal(rt.quantize_rgb8(img), oracle.quantize_rgb8(img))
     assert rt.quantize_rgb8(img).max() == 255
+
+
+def test_bvh_builder_invariants(rt):
+    """the hierarchy of RT_FETCH_BVH, built and checked on the host for all eight traversal orders"""
+    import numpy as np
+    for build in (lambda: rt.build_two_sphere_scene(400), lambda: rt.build_dev_scene(400), lambda: rt.build_final_scene(1, 1200),
+                  lambda: rt.build_final_scene(7, 1200), lambda: rt.build_stress_scene(5, 10000, 1920)):
+        _, sph, _ = build()
+        n_nodes, max_leaf = rt.bvh_validate(sph)
+        assert 1 <= max_leaf <= 4 and len(sph) / 4 <= n_nodes <= 2 * len(sph)
+    same = np.zeros(37, dtype=rt.SPHERE_DTYPE)
+    same["radius"] = 0.5                                  # 37 coincident spheres: no split separates them
+    n_nodes, max_leaf = rt.bvh_validate(same)
+    assert max_leaf <= 4 and n_nodes >= 10
+    assert rt.bvh_validate(same[:0]) == (0, 0)
+    assert rt.bvh_validate(same[:1]) == (1, 1)

@@ -311,3 +311,47 @@ def test_device_ppm_strips_and_extremes(rt):
     assert bytes(text.cpu().numpy()) == body
     assert b"  0 " in body and b"255" in body and b" 99 " in body and b"100 " in body
     world.close()
+
+
+@pytest.mark.parametrize("name,width,spp", [("two", 96, 8), ("dev", 160, 16), ("final", 240, 8), ("stress", 160, 4)])
+def test_bvh_equals_list_scan(rt, oracle, name, width, spp):
+    """RT_FETCH_BVH (closest hit through the bounding-volume hierarchy) against the list scan of
+    the same arithmetic: identical image and identical segment count, and far fewer sphere tests.
+    The list scan itself is pinned to the oracle by the tests above; the final scene here is
+    checked against the oracle directly as well."""
+    if name == "stress":
+        cs, sph, mat = rt.build_stress_scene(5, 3000, width)
+        cs.samples_per_pixel = spp
+        cam = rt.calculate_camera_render_data(cs)
+    else:
+        cs, cam, sph, mat = scene(rt, name, width, spp)
+    w, h = cs.image_width, cs.image_height
+    a, lin_a, st_a = gpu_render(rt, cs, cam, sph, mat, seed=12)
+    b, lin_b, st_b = gpu_render(rt, cs, cam, sph, mat, seed=12, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(a, b) and np.array_equal(lin_a, lin_b)
+    assert int(st_a[rt.STAT_SEGMENTS]) == int(st_b[rt.STAT_SEGMENTS])
+    assert int(st_b[rt.STAT_SPHERE_TESTS]) == int(st_b[rt.STAT_BVH_TESTS]) > 0
+    if len(sph) > 100:
+        assert int(st_b[rt.STAT_BVH_TESTS]) * 10 < int(st_a[rt.STAT_SPHERE_TESTS])
+    if name == "final":
+        ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=12, threads=8)
+        assert np.array_equal(b, ref["image"])
+
+
+def test_bvh_edge_cases(rt):
+    """coincident spheres (ties go to the lowest list index, as the list's strict `<` does), a
+    camera inside a sphere, an empty world, and the precisions the hierarchy does not serve."""
+    cs, cam, sph, mat = scene(rt, "dev", 64, 4)
+    dup = np.concatenate([sph, sph[1:3], sph[1:3]])            # every small sphere three times
+    a, _, _ = gpu_render(rt, cs, cam, dup, mat, seed=2)
+    b, _, _ = gpu_render(rt, cs, cam, dup, mat, seed=2, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(a, b)
+    big = sph.copy(); big["radius"][1] = 50.0                   # the camera sits inside sphere 1
+    a, _, _ = gpu_render(rt, cs, cam, big, mat, seed=2)
+    b, _, _ = gpu_render(rt, cs, cam, big, mat, seed=2, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(a, b)
+    a, _, _ = gpu_render(rt, cs, cam, sph[:0], mat, seed=2)
+    b, _, _ = gpu_render(rt, cs, cam, sph[:0], mat, seed=2, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(a, b)
+    with pytest.raises(rt.RtError):
+        gpu_render(rt, cs, cam, sph, mat, seed=2, sphere_fetch=rt.FETCH_BVH, precision=rt.PRECISION_F64)
