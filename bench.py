@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 F_TEST = 17                 # algorithmic FLOP per ray/sphere test (3 sub, 5+5 dot products, -r^2, h*h-a*c)
 PEAK_FP32_TFLOPS = 157.3    # MI355X vector FP32 peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+GATHER_PEAK_G = 917.8       # --fetch bvh: divergent 16-byte gathers per ns from an L2-resident table, measured by tools/gather_peak
 
 
 def parse():
@@ -230,7 +231,14 @@ def main():
                          "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
         }
         if args.fetch == "bvh":
+            # The traversal is bound by the vector L1's rate of serving per-lane 16-byte gathers that fall into different cache
+            # lines: one per box tested, two per sphere tested.  Peak: the L2-resident rate tools/gather_peak measures on this chip.
+            gathers = bvh_nodes + 2 * bvh_tests
             out["bvh"] = {"boxes_per_segment": bvh_nodes / max(1, segments), "sphere_tests_per_segment": bvh_tests / max(1, segments)}
+            out["roofline"] = {"bound": "vl1d_gather", "achieved": gathers / kernel_s / 1e9, "peak": GATHER_PEAK_G, "unit": "Ggather/s",
+                               "frac": gathers / kernel_s / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>",
+                               "kernel_ms": kernel_s * 1e3, "gathers_per_launch": gathers, "sphere_tests_per_launch": bvh_tests}
+            out["pct_fp32_peak"] = None
         if args.verify:
             # the gathered frame against one single-GPU rt_render_region call over all total_spp samples
             import numpy as np

@@ -93,6 +93,8 @@ struct rt_world_s {
     std::vector<int32_t> h_material;
     void *bvh_nodes = nullptr, *bvh_spheres = nullptr;
     int32_t bvh_n_nodes = 0;
+    bool bvh_built = false;
+    rtk::BvhHost bvh_host;                      // grid and big-sphere list (node and sphere vectors are released after upload)
     void *slabs = nullptr;                      // partial sums of sample chunks 1..
     size_t slab_bytes = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -343,18 +345,28 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         }
     }
 
-    if (fetch == RT_FETCH_BVH && world->bvh_nodes == nullptr && world->n_spheres > 0) {
-        rtk::BvhHost bvh;
+    if (fetch == RT_FETCH_BVH && !world->bvh_built) {
+        rtk::BvhHost &bvh = world->bvh_host;
         rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
-        HIP_TRY(hipMalloc(&world->bvh_nodes, bvh.nodes.size() * sizeof(rtk::BvhNode)));
-        HIP_TRY(hipMalloc(&world->bvh_spheres, bvh.spheres.size() * sizeof(rtk::BvhSphere)));
-        HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&world->bvh_nodes, std::max<size_t>(64, bvh.nodes.size() * sizeof(rtk::BvhNode))));
+        HIP_TRY(hipMalloc(&world->bvh_spheres, std::max<size_t>(64, bvh.spheres.size() * sizeof(rtk::BvhSphere))));
+        if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
+        if (!bvh.spheres.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
         world->bvh_n_nodes = bvh.n_nodes;
+        std::vector<rtk::BvhNode>().swap(bvh.nodes);
+        std::vector<rtk::BvhSphere>().swap(bvh.spheres);
+        world->bvh_built = true;
     }
 
     rtk::RenderParams p{};
     p.bvh_nodes = world->bvh_nodes; p.bvh_spheres = world->bvh_spheres; p.bvh_n_nodes = world->bvh_n_nodes;
+    if (fetch == RT_FETCH_BVH) {
+        const rtk::BvhHost &bvh = world->bvh_host;
+        p.bvh_n_big = bvh.n_big;
+        for (int a = 0; a < 3; ++a) { p.bvh_origin[a] = bvh.origin[a]; p.bvh_step[a] = bvh.step[a]; }
+        static_assert(sizeof(rtk::BvhSphere) == sizeof(p.bvh_big[0]), "big-sphere records are copied bytewise");
+        std::memcpy(p.bvh_big, bvh.big, sizeof(rtk::BvhSphere) * static_cast<size_t>(bvh.n_big));
+    }
     p.sphere_rec = f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32);
     p.sphere_center = f64 ? world->rec64 : world->rec32;
     p.sphere_radius = f64 ? world->rad64 : (precision == RT_PRECISION_F32 ? world->rad32inv : world->rad32);
@@ -567,6 +579,7 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
                 o.stats[RT_STAT_WAVE_ITERATIONS] += h[RT_STAT_WAVE_ITERATIONS];
                 o.stats[RT_STAT_BVH_NODES] += h[RT_STAT_BVH_NODES];
                 o.stats[RT_STAT_BVH_TESTS] += h[RT_STAT_BVH_TESTS];
+                o.stats[7] += h[7]; // diagnostic builds only
                 const int64_t ns = rt_world_last_kernel_ns(d.world);
                 if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
             }
@@ -625,20 +638,26 @@ int32_t rt_bvh_validate(const rt_sphere *spheres, int64_t n_spheres, int64_t *n_
     rtk::build_bvh(rec.data(), k.data(), rad.data(), inv.data(), mat.data(), static_cast<int32_t>(n_spheres), bvh);
     int64_t worst = 0;
     std::vector<int> seen(ns, 0);
+    auto corner = [&](uint16_t q, int a) { return bvh.origin[a] + static_cast<float>(q) * bvh.step[a]; };
     for (int oct = 0; oct < 8; ++oct) {
         const rtk::BvhNode *nodes = bvh.nodes.data() + static_cast<size_t>(oct) * bvh.n_nodes;
         std::fill(seen.begin(), seen.end(), 0);
+        for (int g = 0; g < bvh.n_big; ++g) {
+            if (bvh.big[g].index < 0 || bvh.big[g].index >= static_cast<int>(ns) || seen[bvh.big[g].index]++) return fail(RT_ERR_DEVICE, "big sphere %d appears twice or is out of range", bvh.big[g].index);
+            if (g > 0 && bvh.big[g - 1].index >= bvh.big[g].index) return fail(RT_ERR_DEVICE, "big spheres are not in list order");
+        }
         // every node: skip link ahead and inside the array; boxes of a subtree inside the root of that subtree
         for (int32_t i = 0; i < bvh.n_nodes; ++i) {
             const rtk::BvhNode &nd = nodes[i];
-            if (nd.skip <= i || nd.skip > bvh.n_nodes) return fail(RT_ERR_DEVICE, "octant %d node %d: skip link %d", oct, i, nd.skip);
-            for (int32_t j = i + 1; j < nd.skip; ++j)
+            const bool is_leaf = (nd.link & rtk::BVH_LEAF_FLAG) != 0;
+            const int32_t skip = is_leaf ? i + 1 : static_cast<int32_t>(nd.link);
+            if (skip <= i || skip > bvh.n_nodes) return fail(RT_ERR_DEVICE, "octant %d node %d: skip link %d", oct, i, skip);
+            for (int32_t j = i + 1; j < skip; ++j)
                 for (int a = 0; a < 3; ++a)
-                    if (nodes[j].bmin[a] < nd.bmin[a] || nodes[j].bmax[a] > nd.bmax[a]) return fail(RT_ERR_DEVICE, "octant %d node %d is not inside its ancestor %d", oct, j, i);
-            if (nd.leaf < 0) { if (nd.skip == i + 1) return fail(RT_ERR_DEVICE, "octant %d inner node %d has no subtree", oct, i); continue; }
-            if (nd.skip != i + 1) return fail(RT_ERR_DEVICE, "octant %d leaf %d has a subtree", oct, i);
-            const int first = nd.leaf >> 3, count = nd.leaf & 7;
-            if (count < 1 || count > rtk::BVH_LEAF_MAX || first + count > static_cast<int>(ns)) return fail(RT_ERR_DEVICE, "octant %d leaf %d: range [%d, +%d)", oct, i, first, count);
+                    if (nodes[j].lo[a] < nd.lo[a] || nodes[j].hi[a] > nd.hi[a]) return fail(RT_ERR_DEVICE, "octant %d node %d is not inside its ancestor %d", oct, j, i);
+            if (!is_leaf) { if (skip == i + 1) return fail(RT_ERR_DEVICE, "octant %d inner node %d has no subtree", oct, i); continue; }
+            const int first = static_cast<int>(nd.link & 0x0fffffffu), count = static_cast<int>((nd.link >> 28) & 7u) + 1;
+            if (count > rtk::BVH_LEAF_MAX || first + count > static_cast<int>(bvh.spheres.size())) return fail(RT_ERR_DEVICE, "octant %d leaf %d: range [%d, +%d)", oct, i, first, count);
             worst = std::max<int64_t>(worst, count);
             for (int j = first; j < first + count; ++j) {
                 const rtk::BvhSphere &sp = bvh.spheres[j];
@@ -647,7 +666,7 @@ int32_t rt_bvh_validate(const rt_sphere *spheres, int64_t n_spheres, int64_t *n_
                 const float r = std::fabs(rad[sp.index]);
                 const float c[3] = {rec[4 * sp.index], rec[4 * sp.index + 1], rec[4 * sp.index + 2]};
                 for (int a = 0; a < 3; ++a)
-                    if (!(nd.bmin[a] < c[a] - r && c[a] + r < nd.bmax[a])) return fail(RT_ERR_DEVICE, "octant %d leaf %d does not contain sphere %d", oct, i, sp.index);
+                    if (!(corner(nd.lo[a], a) < c[a] - r && c[a] + r < corner(nd.hi[a], a))) return fail(RT_ERR_DEVICE, "octant %d leaf %d does not contain sphere %d", oct, i, sp.index);
             }
         }
         for (size_t i = 0; i < ns; ++i) if (seen[i] != 1) return fail(RT_ERR_DEVICE, "octant %d: sphere %zu is in %d leaves", oct, i, seen[i]);

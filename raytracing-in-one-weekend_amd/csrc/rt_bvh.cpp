@@ -29,7 +29,6 @@ struct TreeNode {
 };
 
 struct Builder {
-    const float *rec; // {cx, cy, cz, r*r}
     std::vector<Box> boxes;
     std::vector<float> centroid; // 3 per sphere
     std::vector<int> perm;
@@ -99,38 +98,72 @@ struct Builder {
 void build_bvh(const float *centre_r2, const float *k, const float *radius, const float *inv_r, const int32_t *material, int32_t n, BvhHost &out) {
     out = BvhHost();
     if (n <= 0) return;
+    auto record = [&](int s) -> BvhSphere {
+        const float *c = centre_r2 + 4 * static_cast<size_t>(s);
+        return {c[0], c[1], c[2], k[s], c[3], inv_r[s], s, material[s]};
+    };
+    // spheres more than 16 times the median radius stay outside the hierarchy (the largest BVH_BIG_MAX of them)
+    std::vector<float> radii(n);
+    for (int i = 0; i < n; ++i) radii[i] = std::fabs(radius[i]);
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float big_radius = 16.0f * sorted[n / 2];
+    std::vector<int> big;
+    for (int i = 0; i < n; ++i) if (radii[i] > big_radius) big.push_back(i);
+    if (static_cast<int>(big.size()) > BVH_BIG_MAX) {
+        std::partial_sort(big.begin(), big.begin() + BVH_BIG_MAX, big.end(), [&](int a, int b) { return radii[a] > radii[b] || (radii[a] == radii[b] && a < b); });
+        big.resize(BVH_BIG_MAX);
+    }
+    std::sort(big.begin(), big.end());
+    out.n_big = static_cast<int32_t>(big.size());
+    for (size_t i = 0; i < big.size(); ++i) out.big[i] = record(big[i]);
+
     Builder b;
-    b.rec = centre_r2;
-    b.boxes.resize(n); b.centroid.resize(3 * static_cast<size_t>(n)); b.perm.resize(n);
-    std::iota(b.perm.begin(), b.perm.end(), 0);
+    b.boxes.resize(n); b.centroid.resize(3 * static_cast<size_t>(n));
     for (int i = 0; i < n; ++i) {
+        if (std::binary_search(big.begin(), big.end(), i)) continue;
+        b.perm.push_back(i);
         const float *c = centre_r2 + 4 * static_cast<size_t>(i);
-        const float r = std::fabs(radius[i]);
+        const float r = radii[i];
         // The box is wider than the sphere by far more than the rounding of the f32 root
         // evaluation and of the slab test, so every sphere that evaluation can report as hit
         // is reached by the traversal.
         const float pad = std::ldexp(std::max(std::max(std::fabs(c[0]), std::fabs(c[1])), std::fabs(c[2])) + r, -12) + 1e-6f;
         for (int a = 0; a < 3; ++a) { b.boxes[i].lo[a] = c[a] - r - pad; b.boxes[i].hi[a] = c[a] + r + pad; b.centroid[3 * static_cast<size_t>(i) + a] = c[a]; }
     }
-    b.tree.reserve(2 * static_cast<size_t>(n));
-    b.build(0, n);
+    const int m = static_cast<int>(b.perm.size());
+    if (m == 0) return;
+    b.tree.reserve(2 * static_cast<size_t>(m));
+    b.build(0, m);
 
     // leaf spheres in permutation order, ascending list index inside a leaf
-    out.spheres.resize(n);
+    out.spheres.resize(m);
     for (const TreeNode &t : b.tree)
         if (t.left < 0) std::sort(b.perm.begin() + t.first, b.perm.begin() + t.first + t.count);
-    for (int i = 0; i < n; ++i) {
-        const int s = b.perm[i];
-        const float *c = centre_r2 + 4 * static_cast<size_t>(s);
-        out.spheres[i] = {c[0], c[1], c[2], k[s], c[3], inv_r[s], s, material[s]};
+    for (int i = 0; i < m; ++i) out.spheres[i] = record(b.perm[i]);
+
+    // quantisation grid over the root box; corners are rounded outwards by one extra step so that
+    // the f32 evaluation origin + q*step never lands inside the exact box
+    const Box &root = b.tree[0].box;
+    double org[3], stp[3];
+    for (int a = 0; a < 3; ++a) {
+        org[a] = root.lo[a];
+        stp[a] = std::max((double(root.hi[a]) - root.lo[a]) / 65533.0, 1e-30);
+        out.origin[a] = static_cast<float>(org[a]);
+        out.step[a] = static_cast<float>(stp[a]);
+        // the grid the kernel evaluates is the rounded f32 one: re-derive it so that quantisation uses the same numbers
+        org[a] = out.origin[a]; stp[a] = out.step[a];
     }
+    auto quant_lo = [&](float v, int a) { return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, std::floor((double(v) - org[a]) / stp[a]) - 1.0))); };
+    auto quant_hi = [&](float v, int a) { return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, std::ceil((double(v) - org[a]) / stp[a]) + 1.0))); };
+
     const int32_t n_nodes = static_cast<int32_t>(b.tree.size());
     out.n_nodes = n_nodes;
     out.nodes.resize(8 * static_cast<size_t>(n_nodes));
     for (int oct = 0; oct < 8; ++oct) {
         BvhNode *dst = out.nodes.data() + static_cast<size_t>(oct) * n_nodes;
         int32_t next = 0;
-        // iterative depth-first emission; a node's skip link is the index after its subtree
+        // iterative depth-first emission; an inner node's skip link is the index after its subtree
         struct Frame { int node; int32_t slot; int stage; };
         std::vector<Frame> stack;
         stack.push_back({0, -1, 0});
@@ -140,9 +173,12 @@ void build_bvh(const float *centre_r2, const float *k, const float *radius, cons
             if (f.stage == 0) {
                 f.slot = next++;
                 BvhNode &o = dst[f.slot];
-                for (int a = 0; a < 3; ++a) { o.bmin[a] = t.box.lo[a]; o.bmax[a] = t.box.hi[a]; }
-                o.leaf = t.left < 0 ? t.first * 8 + t.count : -1;
-                if (t.left < 0) { o.skip = next; stack.pop_back(); continue; }
+                for (int a = 0; a < 3; ++a) { o.lo[a] = quant_lo(t.box.lo[a], a); o.hi[a] = quant_hi(t.box.hi[a], a); }
+                if (t.left < 0) {
+                    o.link = BVH_LEAF_FLAG | (static_cast<uint32_t>(t.count - 1) << 28) | static_cast<uint32_t>(t.first);
+                    stack.pop_back();
+                    continue;
+                }
                 f.stage = 1;
                 const bool negative = (oct >> t.axis) & 1; // direction runs from large to small coordinates: right child is nearer
                 stack.push_back({negative ? t.right : t.left, -1, 0});
@@ -151,7 +187,7 @@ void build_bvh(const float *centre_r2, const float *k, const float *radius, cons
                 const bool negative = (oct >> t.axis) & 1;
                 stack.push_back({negative ? t.left : t.right, -1, 0});
             } else {
-                dst[f.slot].skip = next;
+                dst[f.slot].link = static_cast<uint32_t>(next);
                 stack.pop_back();
             }
         }

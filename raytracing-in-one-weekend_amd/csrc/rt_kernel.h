@@ -47,10 +47,14 @@ struct RenderParams {
     const void *material_rec;   // per material {albedo.xyz, param1} in float4 / double4
     const int32_t *material_type;
     int32_t n_spheres;          // padded to a multiple of SCAN_STEP (pad records have r*r = -inf); GROUP more follow
-    // FETCH_BVH: the hierarchy (rt_bvh.h): 8 octant orders of bvh_n_nodes nodes (two float4 each), leaf spheres (two float4 each)
+    // FETCH_BVH: the hierarchy (rt_bvh.h): 8 octant orders of bvh_n_nodes 16-byte nodes, leaf spheres (two float4 each),
+    // the quantisation grid of the node boxes, and the spheres kept outside the hierarchy
     const void *bvh_nodes;
     const void *bvh_spheres;
     int32_t bvh_n_nodes;
+    int32_t bvh_n_big;
+    float bvh_origin[3], bvh_step[3];
+    float bvh_big[8][8];        // {cx, cy, cz, K, r*r, 1/r, index, material} (the last two as integer bits)
     // image and work
     int32_t width, height;
     int32_t min_x, min_y, max_x, max_y; // region, half open

@@ -238,6 +238,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
     V3<Real> start_center = {Real(0), Real(0), Real(0)};
     uint32_t segments = 0, started = 0;
     uint32_t bvh_nodes = 0, bvh_tests = 0; // hierarchy mode: boxes and spheres this lane tested
+#ifdef RT_DIAG_BVH
+    uint32_t bvh_wave_steps = 0; // diagnostic build: trips of the traversal loop counted by the lowest active lane
+#endif
 #ifdef RT_DIAG_COUNTERS
     // diagnostic build: how often the scan leaves its straight-line code
     uint32_t diag_entries = 0, diag_resolves = 0, diag_parked = 0;
@@ -425,50 +428,67 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 // (main.odin:542), so the result is the list scan's bit for bit: the boxes are padded
                 // well beyond the rounding of the root evaluation, hence every sphere that
                 // evaluation reports as hit is reached.
-                const float4 *__restrict__ nodes = static_cast<const float4 *>(P.bvh_nodes) +
-                    static_cast<size_t>((rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0)) * static_cast<size_t>(P.bvh_n_nodes) * 2;
+                // one sphere through the two stages of the list scan (same operations, same order)
+                auto test_sphere = [&](const float cx, const float cy, const float cz, const float K, const float r2, const int index) {
+                    ++bvh_tests;
+                    // stage 1: the list scan's filter
+                    const float h = fma_rn(cz, rd.z, fma_rn(cy, rd.y, fma_rn(cx, rd.x, -d_o)));
+                    const float m = fma_rn(K, a, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
+                    const float disc = fma_rn(h, h, -m);
+                    if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) return;
+                    // stage 2: the roots of `resolve`
+                    const float ocx = cx - ro.x, ocy = cy - ro.y, ocz = cz - ro.z;
+                    const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a;
+                    const float lx = fma_rn(-q, rd.x, ocx), ly = fma_rn(-q, rd.y, ocy), lz = fma_rn(-q, rd.z, ocz);
+                    const float D = r2 - fma_rn(lz, lz, fma_rn(ly, ly, lx * lx));
+                    if (!(D >= 0.0f)) return;
+                    const float sq = sqrt_rn(D * inv_a);
+                    float root = q - sq;
+                    if (root < t_min) root = q + sq; // the near root is behind t_min: the far one (main.odin:253-257)
+                    if (root < t_min) return;
+                    // in list order the first sphere of the smallest root wins; the start sphere was tested before the list
+                    if (root < closest || (root == closest && hit != start_sphere && index < hit)) { closest = root; hit = index; }
+                };
+                // spheres kept outside the hierarchy (far larger than the rest): every segment tests them
+                for (int g = 0; g < P.bvh_n_big; ++g)
+                    test_sphere(P.bvh_big[g][0], P.bvh_big[g][1], P.bvh_big[g][2], P.bvh_big[g][3], P.bvh_big[g][4], __float_as_int(P.bvh_big[g][6]));
+
+                const uint4 *__restrict__ nodes = static_cast<const uint4 *>(P.bvh_nodes) +
+#ifdef RT_DIAG_BVH_ONE_ORDER
+                    0;
+#else
+                    static_cast<size_t>((rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0)) * static_cast<size_t>(P.bvh_n_nodes);
+#endif
                 const float4 *__restrict__ leaves = static_cast<const float4 *>(P.bvh_spheres);
+                // box corner = origin + q*step, so its slab parameter (corner - o)/d is q*A + B
                 const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
+                const float ax = P.bvh_step[0] * ix, ay = P.bvh_step[1] * iy, az = P.bvh_step[2] * iz;
+                const float bx = (P.bvh_origin[0] - ro.x) * ix, by = (P.bvh_origin[1] - ro.y) * iy, bz = (P.bvh_origin[2] - ro.z) * iz;
                 int node = 0;
                 while (node < P.bvh_n_nodes) {
-                    const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
+                    const uint4 nd = nodes[node]; // {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, link}
                     ++bvh_nodes;
-                    // slab test; a NaN (0 * inf: origin on a slab plane of an axis the ray does not move along) is ignored by min/max
-                    const float tx0 = (lo.x - ro.x) * ix, tx1 = (hi.x - ro.x) * ix;
-                    const float ty0 = (lo.y - ro.y) * iy, ty1 = (hi.y - ro.y) * iy;
-                    const float tz0 = (lo.z - ro.z) * iz, tz1 = (hi.z - ro.z) * iz;
+#ifdef RT_DIAG_BVH
+                    if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++bvh_wave_steps; // one lane per trip of the wave
+#endif
+                    // slab test; a NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box
+                    const float tx0 = fma_rn(static_cast<float>(nd.x & 0xffffu), ax, bx), tx1 = fma_rn(static_cast<float>(nd.y >> 16), ax, bx);
+                    const float ty0 = fma_rn(static_cast<float>(nd.x >> 16), ay, by), ty1 = fma_rn(static_cast<float>(nd.z & 0xffffu), ay, by);
+                    const float tz0 = fma_rn(static_cast<float>(nd.y & 0xffffu), az, bz), tz1 = fma_rn(static_cast<float>(nd.z >> 16), az, bz);
                     const float t_in = max_num(max_num(min_num(tx0, tx1), min_num(ty0, ty1)), max_num(min_num(tz0, tz1), 0.0f));
                     const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), closest));
+                    const bool is_leaf = (nd.w & 0x80000000u) != 0u;
                     if (t_in <= t_out) {
-                        const int leaf = __float_as_int(hi.w);
-                        if (leaf >= 0) {
-                            const int first = leaf >> 3, count = leaf & 7;
+                        if (is_leaf) {
+                            const int first = static_cast<int>(nd.w & 0x0fffffffu), count = static_cast<int>((nd.w >> 28) & 7u) + 1;
                             for (int j = first; j < first + count; ++j) {
                                 const float4 s0 = leaves[2 * j], s1 = leaves[2 * j + 1]; // {centre, K} {r*r, 1/r, index, material}
-                                const int index = __float_as_int(s1.z);
-                                ++bvh_tests;
-                                // stage 1: the list scan's filter
-                                const float h = fma_rn(s0.z, rd.z, fma_rn(s0.y, rd.y, fma_rn(s0.x, rd.x, -d_o)));
-                                const float m = fma_rn(s0.w, a, fma_rn(s0.z, aoz, fma_rn(s0.y, aoy, fma_rn(s0.x, aox, aoo))));
-                                const float disc = fma_rn(h, h, -m);
-                                if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) continue;
-                                // stage 2: the roots of `resolve`
-                                const float ocx = s0.x - ro.x, ocy = s0.y - ro.y, ocz = s0.z - ro.z;
-                                const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a;
-                                const float lx = fma_rn(-q, rd.x, ocx), ly = fma_rn(-q, rd.y, ocy), lz = fma_rn(-q, rd.z, ocz);
-                                const float D = s1.x - fma_rn(lz, lz, fma_rn(ly, ly, lx * lx));
-                                if (!(D >= 0.0f)) continue;
-                                const float sq = sqrt_rn(D * inv_a);
-                                float root = q - sq;
-                                if (root < t_min) root = q + sq; // the near root is behind t_min: the far one (main.odin:253-257)
-                                if (root < t_min) continue;
-                                // in list order the first sphere of the smallest root wins; the start sphere was tested before the list
-                                if (root < closest || (root == closest && hit != start_sphere && index < hit)) { closest = root; hit = index; }
+                                test_sphere(s0.x, s0.y, s0.z, s0.w, s1.x, __float_as_int(s1.z));
                             }
                         }
                         node = node + 1;
                     } else {
-                        node = __float_as_int(lo.w);
+                        node = is_leaf ? node + 1 : static_cast<int>(nd.w);
                     }
                 }
             } else {
@@ -647,6 +667,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 atomicAdd(&P.stats[5], static_cast<unsigned long long>(nb));
                 atomicAdd(&P.stats[6], static_cast<unsigned long long>(nt));
             }
+#ifdef RT_DIAG_BVH
+            uint32_t ws = bvh_wave_steps;
+            for (int off = 32; off > 0; off >>= 1) ws += __shfl_xor(ws, off, 64);
+            if (lane == 0) atomicAdd(&P.stats[7], static_cast<unsigned long long>(ws));
+#endif
         }
 #ifdef RT_DIAG_COUNTERS
         // entries: per wave (uniform, take lane 0's); resolves: wave-level calls (max over lanes approximates); parked: lane total
