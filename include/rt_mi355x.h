@@ -44,6 +44,12 @@ typedef struct { rt_v3 center; double radius; int64_t material_index; } rt_spher
 #define RT_MATERIAL_LAMBERTIAN 0
 #define RT_MATERIAL_METALLIC 1
 #define RT_MATERIAL_DIELECTRIC 2
+/* metallic_proc as compiled with -define:USE_METAL_FRESNEL=true (main.odin:324-347) and the
+ * METAL_FRESNEL_KIND the reference selects (2, :332): the attenuation becomes
+ * lerp(albedo, 1, reflectance_fresnel(cos, sin, 1.0, 1.27035)) (main.odin:84-109, :341-347).
+ * The reference switches all metals at compile time; here it is a material type, so a host built
+ * with that flag passes 3 where it passes 1 today.  Same data: albedo, param1 = fuzz. */
+#define RT_MATERIAL_METALLIC_FRESNEL 3
 
 /* material :: struct {type: material_type, data: {albedo: v3, param1: f64}}
  * param1 = fuzz for metallic, refractive index for dielectric       main.odin:274-289 (40 B) */

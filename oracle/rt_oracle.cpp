@@ -294,13 +294,38 @@ inline scatter_result<Real> lambertian_proc(const material_t<Real> &m, const ray
     if (is_near_zero(dir)) dir = hit.normal;
     return {{hit.p, dir}, m.albedo, true};
 }
-/* metallic_proc, USE_METAL_FRESNEL = false branch  main.odin:315-323, :348-353 */
+/* reflectance_fresnel  main.odin:84-109 */
+template <class Real> inline Real reflectance_fresnel(Real cos_i, Real sin_i, Real n1, Real n2) {
+    Real subexp = (n1 / n2) * sin_i;
+    subexp = Real(1) - subexp * subexp;
+    subexp = std::sqrt(subexp);
+    Real x1 = n1 * cos_i, x2 = n2 * subexp;
+    Real r_s = (x1 - x2);
+    r_s /= (x1 + x2);
+    r_s *= r_s;
+    x1 = n1 * subexp; x2 = n2 * cos_i;
+    Real r_p = (x1 - x2);
+    r_p /= (x1 + x2);
+    r_p *= r_p;
+    return (r_s + r_p) * Real(0.5);
+}
+/* metallic_proc  main.odin:315-353.  fresnel = false: the USE_METAL_FRESNEL = false branch (:348-350);
+ * true: that flag set, with METAL_FRESNEL_KIND 2 as the reference selects it (:326-328, :341-347). */
 template <class Real, bool FAST = false>
-inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
+inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g, bool fresnel) {
     Real fuzz = m.param1;
     vec3<Real> dir = normalize_as<Real, FAST>(reflect(ray_in.direction, hit.normal));
     dir = dir + fuzz * random_unit_vector<Real, FAST>(g);
-    return {{hit.p, dir}, m.albedo, dot(dir, hit.normal) > Real(0)};
+    vec3<Real> attenuation = m.albedo;
+    if (fresnel) {
+        Real cos_theta = dot(-normalize_as<Real, FAST>(ray_in.direction), hit.normal);
+        cos_theta = std::min(cos_theta, Real(1));
+        const Real sin_theta = std::sqrt(Real(1) - cos_theta * cos_theta);
+        const Real reflection_factor = reflectance_fresnel<Real>(cos_theta, sin_theta, Real(1), static_cast<Real>(1.27035));
+        const vec3<Real> one{Real(1), Real(1), Real(1)};
+        attenuation = m.albedo * (Real(1) - reflection_factor) + one * reflection_factor; /* math.lerp(albedo, 1, t) */
+    }
+    return {{hit.p, dir}, attenuation, dot(dir, hit.normal) > Real(0)};
 }
 /* dielectric_proc  main.odin:356-400 */
 template <class Real, bool FAST = false>
@@ -328,7 +353,8 @@ template <class Real, bool FAST = false>
 inline scatter_result<Real> material_scatter(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
     switch (m.type) {
     case RT_MATERIAL_LAMBERTIAN: return lambertian_proc<Real, FAST>(m, ray_in, hit, g);
-    case RT_MATERIAL_METALLIC: return metallic_proc<Real, FAST>(m, ray_in, hit, g);
+    case RT_MATERIAL_METALLIC: return metallic_proc<Real, FAST>(m, ray_in, hit, g, false);
+    case RT_MATERIAL_METALLIC_FRESNEL: return metallic_proc<Real, FAST>(m, ray_in, hit, g, true);
     default: return dielectric_proc<Real, FAST>(m, ray_in, hit, g);
     }
 }

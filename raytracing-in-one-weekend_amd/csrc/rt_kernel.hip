@@ -601,6 +601,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                     // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
                     dir = normalize<Real, FMA>(reflect(rd, nrm));
                     dir = dir + m.w * ruv;
+                    if (mtype == 3) {
+                        // USE_METAL_FRESNEL, METAL_FRESNEL_KIND 2 (main.odin:326-328, :341-347, :84-109)
+                        Real cos_theta = dot(-normalize<Real, FMA>(rd), nrm);
+                        cos_theta = min_std(cos_theta, Real(1));
+                        const Real sin_theta = sqrt_rn(Real(1) - cos_theta * cos_theta);
+                        const Real n1 = Real(1), n2 = static_cast<Real>(1.27035);
+                        Real sub = (n1 / n2) * sin_theta;
+                        sub = Real(1) - sub * sub;
+                        sub = sqrt_rn(sub);
+                        Real x1 = n1 * cos_theta, x2 = n2 * sub;
+                        Real rs = (x1 - x2);
+                        rs = rs / (x1 + x2);
+                        rs = rs * rs;
+                        x1 = n1 * sub; x2 = n2 * cos_theta;
+                        Real rp = (x1 - x2);
+                        rp = rp / (x1 + x2);
+                        rp = rp * rp;
+                        const Real refl = (rs + rp) * Real(0.5);
+                        // math.lerp(albedo, {1,1,1}, t) = albedo*(1-t) + 1*t
+                        atten = atten * (Real(1) - refl) + V3<Real>{Real(1), Real(1), Real(1)} * refl;
+                    }
                     ok = dot(dir, nrm) > Real(0);
                 }
             }

@@ -160,6 +160,21 @@ def ray_sphere_intersection(ro, rd, center, radius, t_min, t_max):
     return root
 
 
+def reflectance_fresnel(cos_i, sin_i, n1, n2):  # main.odin:84-109
+    subexp = (n1 / n2) * sin_i
+    subexp = 1.0 - subexp * subexp
+    subexp = math.sqrt(subexp)
+    x1, x2 = n1 * cos_i, n2 * subexp
+    r_s = (x1 - x2)
+    r_s /= (x1 + x2)
+    r_s *= r_s
+    x1, x2 = n1 * subexp, n2 * cos_i
+    r_p = (x1 - x2)
+    r_p /= (x1 + x2)
+    r_p *= r_p
+    return (r_s + r_p) * 0.5
+
+
 # ---- materials (main.odin:292-410); material = (type, albedo, param1)
 def material_scatter(material, ro, rd, hit_p, hit_n, front_face, gen):
     mtype, albedo, param1 = material
@@ -168,10 +183,16 @@ def material_scatter(material, ro, rd, hit_p, hit_n, front_face, gen):
         if is_near_zero(out):
             out = hit_n
         return (hit_p, out), albedo, True
-    if mtype == 1:
+    if mtype in (1, 3):
         out = normalize(reflect(rd, hit_n))
         out = vadd(out, smul(param1, random_unit_vector(gen)))
-        return (hit_p, out), albedo, dot(out, hit_n) > 0
+        attenuation = albedo
+        if mtype == 3:  # USE_METAL_FRESNEL with METAL_FRESNEL_KIND 2 (main.odin:326-328, :341-347)
+            cos_theta = min(dot(neg(normalize(rd)), hit_n), 1.0)
+            sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
+            t = reflectance_fresnel(cos_theta, sin_theta, 1.0, 1.27035)
+            attenuation = vadd(smul(1.0 - t, albedo), smul(t, (1.0, 1.0, 1.0)))  # math.lerp(albedo, 1, t)
+        return (hit_p, out), attenuation, dot(out, hit_n) > 0
     ri = param1
     src = 1.0 if ri >= 1.0 else 1.0 / ri
     dst = ri if ri >= 1.0 else 1.0

@@ -355,3 +355,27 @@ def test_bvh_edge_cases(rt):
     assert np.array_equal(a, b)
     with pytest.raises(rt.RtError):
         gpu_render(rt, cs, cam, sph, mat, seed=2, sphere_fetch=rt.FETCH_BVH, precision=rt.PRECISION_F64)
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_metal_fresnel_material_type(rt, oracle, precision):
+    """RT_MATERIAL_METALLIC_FRESNEL (the reference's USE_METAL_FRESNEL build, main.odin:324-347):
+    GPU against the oracle, bitwise, with every metal of the scene switched to it."""
+    for name, width, spp in (("dev", 64, 8), ("final", 96, 4)):
+        cs, cam, sph, mat = scene(rt, name, width, spp)
+        mat = mat.copy()
+        metals = mat["type"] == 1
+        assert metals.any()
+        mat["type"][metals] = 3
+        w, h = cs.image_width, cs.image_height
+        image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=6, precision=precision, sample_chunks=1)
+        ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=6)
+        assert np.array_equal(image, ref["image"]) and np.array_equal(linear, ref["linear"])
+        assert int(stats[0]) == int(ref["stats"][0])
+        if precision == 0:
+            bvh, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=6, sphere_fetch=rt.FETCH_BVH)
+            assert np.array_equal(bvh, image)
+    bad = mat.copy()
+    bad["type"][0] = 4
+    with pytest.raises(rt.RtError):
+        gpu_render(rt, cs, cam, sph, bad, seed=6)

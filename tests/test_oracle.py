@@ -76,6 +76,8 @@ MATERIAL_CASES = [
     ("lambertian", (0, (0.8, 0.6, 0.2), 0.0), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
     ("metal fuzz 0", (1, (0.7, 0.6, 0.5), 0.0), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
     ("metal fuzz 1 grazing (may absorb)", (1, (0.8, 0.6, 0.2), 1.0), (1.0, -0.05, 0.0), (0.0, 1.0, 0.0), True),
+    ("metal with the Fresnel attenuation (USE_METAL_FRESNEL)", (3, (0.7, 0.6, 0.5), 0.1), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
+    ("Fresnel metal, grazing", (3, (0.8, 0.6, 0.2), 0.0), (1.0, -0.02, 0.3), (0.0, 1.0, 0.0), True),
     ("glass front face", (2, (0.0, 0.0, 0.0), 1.5), (0.3, -1.0, 0.2), (0.0, 1.0, 0.0), True),
     ("glass back face, steep: total internal reflection", (2, (0.0, 0.0, 0.0), 1.5), (1.0, -0.2, 0.0), (0.0, 1.0, 0.0), False),
     ("glass back face, shallow: refracts or reflects", (2, (0.0, 0.0, 0.0), 1.5), (0.1, -1.0, 0.0), (0.0, 1.0, 0.0), False),
@@ -96,8 +98,43 @@ def test_scatter_against_pyref(oracle, name, material, ray_d, normal, front):
         assert ok == pok, name
         assert tuple(o_) == po and tuple(d_) == pd and tuple(att) == patt, name
         absorbed += not ok
-    if material[0] != 1:
+    if material[0] not in (1, 3):
         assert absorbed == 0  # only metal can absorb (main.odin:351)
+
+
+def test_metal_fresnel_attenuation_closed_form(oracle):
+    """USE_METAL_FRESNEL, kind 2 (main.odin:341-347, :84-109): at normal incidence both polarisations
+    give ((1 - n)/(1 + n))^2 with n = 1.27035, at grazing incidence the reflectance tends to 1 and the
+    attenuation to white; the plain metal keeps its albedo (main.odin:349)."""
+    albedo = (0.8, 0.6, 0.2)
+    n = 1.27035
+    r0 = ((1.0 - n) / (1.0 + n)) ** 2
+    for precision, tol in ((1, 1e-15), (0, 1e-6), (2, 1e-6)):
+        _, _, att, ok = oracle.material_scatter(precision, (3, albedo, 0.0), (0, 2, 0), (0.0, -1.0, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert ok and np.allclose(att, [a * (1 - r0) + r0 for a in albedo], rtol=0, atol=tol)
+        _, _, att, _ = oracle.material_scatter(precision, (3, albedo, 0.0), (0, 2, 0), (1.0, -1e-4, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert all(0.99 < a <= 1.0 for a in att)
+        _, _, att, _ = oracle.material_scatter(precision, (1, albedo, 0.0), (0, 2, 0), (1.0, -1e-4, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert np.allclose(att, albedo, rtol=0, atol=tol)
+
+
+def test_metal_fresnel_render_against_pyref(rt, oracle):
+    """the three-material scene with its gold switched to the Fresnel variant: f64 oracle = pure-Python restatement"""
+    cs, sph, mat = rt.build_dev_scene(20)
+    cs.samples_per_pixel = 3
+    mat = mat.copy()
+    assert int(mat["type"][4]) == 1
+    mat["type"][4] = 3
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    spl, ml = as_lists(sph, mat)
+    got, seg = pyref.render_region(w, h, (0, 0, w, h), cam_dict(cam), spl, ml, 5)
+    r = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=5)
+    for (u, v), c in got.items():
+        assert tuple(r["image"][v, u]) == c
+    assert int(r["stats"][0]) == seg
+    plain = oracle.render_region(w, h, (0, 0, w, h), cam, sph, rt.build_dev_scene(20)[2], precision=1, seed=5)
+    assert int(plain["stats"][0]) == seg and not np.array_equal(plain["image"], r["image"])  # same paths, brighter gold
 
 
 def test_total_internal_reflection_draws_nothing(oracle):
