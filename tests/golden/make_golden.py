@@ -2,7 +2,7 @@
 """Generates the fixtures under tests/golden/.  Run from the repo root: python tests/golden/make_golden.py
 
 rng_kat.json            counter-RNG known answers, computed by the pure-Python restatement (tests/pyref.py)
-render_<scene>_f64.npz  32x18, 4 spp gamma image + linear means of BASELINE configs 1 ("two") and 2 ("dev"),
+render_<scene>_f64.npz  32x18, 4 spp gamma image + linear means of the two small benchmark configurations ("two": two lambertian spheres; "dev": the three-material scene),
                         computed by tests/pyref.py in IEEE f64 -- independent of the C++ oracle and of the GPU
 render_<scene>_f32.npz  the same renders in the two f32 arithmetics, computed by the C++ oracle (regression pins)
 intersection_kat.json   ray_sphere_intersection cases with closed-form answers

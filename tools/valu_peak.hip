@@ -104,6 +104,29 @@ __global__ void sphere_mix(float *out, float b, float c) {
     if (best == 123.456f) out[0] = best;
 }
 
+// issue cost of the instructions the non-scan part of the renderer is made of (RNG hash, square
+// roots, reciprocals): the same dependent-free stream with one instruction swapped in
+#define OP_KERNEL(name, text, constraint_b)                                                         \
+    __global__ void name(float *out, float b, float c) {                                            \
+        uint32_t acc[ACC];                                                                          \
+        const uint32_t ub = __float_as_uint(b) | 1u;                                                \
+        (void)c;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < ACC; ++i) acc[i] = __float_as_uint(1.0f + threadIdx.x * 1e-3f + i); \
+        for (int it = 0; it < ITERS; ++it) {                                                        \
+            _Pragma("unroll") for (int i = 0; i < ACC; ++i) asm volatile(text : "+v"(acc[i]) : constraint_b(ub)); \
+        }                                                                                           \
+        uint32_t s = 0;                                                                             \
+        _Pragma("unroll") for (int i = 0; i < ACC; ++i) s += acc[i];                                \
+        if (s == 0x12345678u) out[0] = 1.0f;                                                        \
+    }
+OP_KERNEL(op_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1", "v")
+OP_KERNEL(op_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1", "v")
+OP_KERNEL(op_xor, "v_xor_b32 %0, %0, %1", "v")
+OP_KERNEL(op_sqrt, "v_sqrt_f32 %0, %0", "v")
+OP_KERNEL(op_rcp, "v_rcp_f32 %0, %0", "v")
+OP_KERNEL(op_cvt, "v_cvt_f32_u32 %0, %0", "v")
+OP_KERNEL(op_max, "v_max_f32 %0, %0, %1", "v")
+
 template <class K> double run(K kernel, int blocks_per_cu, int threads, float *d) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -142,6 +165,18 @@ int main() {
         if (flops / ts > best_scalar) best_scalar = flops / ts;
         if (flops / tp > best_packed) best_packed = flops / tp;
         if (mix_flops / tm > best_mix) best_mix = mix_flops / tm;
+    }
+    {
+        // cycles per wave64 instruction on one SIMD at 8 waves per SIMD, clock from the device properties
+        const double insts = 256.0 * 8 * 4 * double(ITERS) * ACC; // wave-instructions per launch: CUs * blocks * waves * ...
+        const double hz = prop.clockRate * 1e3;
+        struct { const char *name; double t; } ops[] = {
+            {"v_xor_b32", run(op_xor, 8, 256, d)}, {"v_max_f32", run(op_max, 8, 256, d)}, {"v_cvt_f32_u32", run(op_cvt, 8, 256, d)},
+            {"v_mul_u32_u24", run(op_mul_u32_u24, 8, 256, d)}, {"v_mul_lo_u32", run(op_mul_lo_u32, 8, 256, d)},
+            {"v_sqrt_f32", run(op_sqrt, 8, 256, d)}, {"v_rcp_f32", run(op_rcp, 8, 256, d)}};
+        printf("cycles per wave64 instruction per SIMD (8 waves/SIMD):");
+        for (auto &o : ops) printf("  %s %.1f", o.name, o.t * hz * 1024.0 / insts);
+        printf("\n");
     }
     printf("{\"v_fma_f32_tflops\": %.2f, \"v_pk_fma_f32_tflops\": %.2f, \"sphere_mix_tflops\": %.2f, \"spec_tflops\": 157.3}\n",
            best_scalar * 1e-12, best_packed * 1e-12, best_mix * 1e-12);
