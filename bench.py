@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--scene", default="final", choices=["final", "dev", "stress"])
     ap.add_argument("--partition", default="samples", choices=["samples", "rows"])
-    ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds", "bvh"],
+    ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds", "bvh", "bvh-global"],
                     help="bvh: closest hit through the bounding-volume hierarchy (not the headline: the roofline then counts the tests carried out)")
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="after timing, rank 0 re-renders the frame in one rt_render_region call and compares bitwise")
@@ -150,7 +150,7 @@ def main():
     cs.samples_per_pixel = args.spp
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
-    fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS, "bvh": rt.FETCH_BVH}[args.fetch]
+    fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS, "bvh": rt.FETCH_BVH, "bvh-global": rt.FETCH_BVH_GLOBAL}[args.fetch]
 
     world = rt.World(sph, mat, device=local_rank)
     accum = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums: exact, so the all-reduce is order-independent
@@ -212,7 +212,7 @@ def main():
 
     if rank == 0:
         # list scan: every segment tests every sphere; hierarchy: the tests the traversal carried out (counted by the kernel)
-        tests_rank = bvh_tests if args.fetch == "bvh" else segments * len(sph)
+        tests_rank = bvh_tests if args.fetch.startswith("bvh") else segments * len(sph)
         achieved = F_TEST * tests_rank / kernel_s / 1e12
         out = {
             "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak",
@@ -226,11 +226,11 @@ def main():
             "segments_per_sample": segments / max(1, samples_rank),
             "lane_utilization": segments / max(1, 64 * wave_iters),
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic(args) if args.fetch != "bvh" else None,
-                         "kernel": "render_kernel<float, fma, bvh>" if args.fetch == "bvh" else "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
+                         "traffic": measured_traffic(args) if not args.fetch.startswith("bvh") else None,
+                         "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
                          "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
         }
-        if args.fetch == "bvh":
+        if args.fetch.startswith("bvh"):
             # The traversal is bound by the vector L1's rate of serving per-lane 16-byte gathers that fall into different cache
             # lines: one per box tested, two per sphere tested.  Peak: the L2-resident rate tools/gather_peak measures on this chip.
             gathers = bvh_nodes + 2 * bvh_tests

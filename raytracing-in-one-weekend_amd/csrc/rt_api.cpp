@@ -91,7 +91,7 @@ struct rt_world_s {
     // RT_FETCH_BVH: built and uploaded on first use from the host copies kept here
     std::vector<float> h_rec32, h_k, h_rad32, h_rad32inv;
     std::vector<int32_t> h_material;
-    void *bvh_nodes = nullptr, *bvh_spheres = nullptr;
+    void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr;
     int32_t bvh_n_nodes = 0;
     bool bvh_built = false;
     rtk::BvhHost bvh_host;                      // grid and big-sphere list (node and sphere vectors are released after upload)
@@ -294,7 +294,7 @@ int32_t rt_world_destroy(rt_world *w) {
     if (w == nullptr) return RT_OK;
     DeviceGuard guard;
     (void)guard.enter(w->device);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue, w->bvh_nodes, w->bvh_spheres};
+    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue, w->bvh_nodes, w->bvh_spheres, w->bvh_lds_boxes, w->bvh_lds_links};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
@@ -308,7 +308,9 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
                              int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
     if (world == nullptr || cam == nullptr || d_accum == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, cam or d_accum is NULL");
     if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
-    if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
+    if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH_GLOBAL) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
+    const bool bvh_global_only = sphere_fetch == RT_FETCH_BVH_GLOBAL;
+    if (bvh_global_only) sphere_fetch = RT_FETCH_BVH;
     if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32) return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32 only");
     if (sample_begin < 0 || sample_count < 0 || sample_begin + sample_count > (int64_t(1) << 32) - 2) return fail(RT_ERR_INVALID_ARGUMENT, "samples [%lld, +%lld) outside [0, 2^32-2)", (long long)sample_begin, (long long)sample_count);
     if (cam->max_ray_bounces < 0 || cam->max_ray_bounces > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "max_ray_bounces %lld outside [0, 2^20]", (long long)cam->max_ray_bounces);
@@ -353,6 +355,14 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
         if (!bvh.spheres.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
         world->bvh_n_nodes = bvh.n_nodes;
+        if (!bvh.lds_boxes.empty()) {
+            HIP_TRY(hipMalloc(&world->bvh_lds_boxes, bvh.lds_boxes.size() * sizeof(rtk::BvhBoxLds)));
+            HIP_TRY(hipMalloc(&world->bvh_lds_links, bvh.lds_links.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(world->bvh_lds_boxes, bvh.lds_boxes.data(), bvh.lds_boxes.size() * sizeof(rtk::BvhBoxLds), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(world->bvh_lds_links, bvh.lds_links.data(), bvh.lds_links.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        std::vector<rtk::BvhBoxLds>().swap(bvh.lds_boxes);
+        std::vector<uint32_t>().swap(bvh.lds_links);
         std::vector<rtk::BvhNode>().swap(bvh.nodes);
         std::vector<rtk::BvhSphere>().swap(bvh.spheres);
         world->bvh_built = true;
@@ -360,6 +370,7 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
 
     rtk::RenderParams p{};
     p.bvh_nodes = world->bvh_nodes; p.bvh_spheres = world->bvh_spheres; p.bvh_n_nodes = world->bvh_n_nodes;
+    if (!bvh_global_only) { p.bvh_lds_boxes = world->bvh_lds_boxes; p.bvh_lds_links = world->bvh_lds_links; }
     if (fetch == RT_FETCH_BVH) {
         const rtk::BvhHost &bvh = world->bvh_host;
         p.bvh_n_big = bvh.n_big;
@@ -587,7 +598,7 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
         if (e != hipSuccess) result = fail(RT_ERR_DEVICE, "collecting from device %d failed: %s", d.device, hipGetErrorString(e));
     }
     if (result == RT_OK && o.stats)
-        o.stats[RT_STAT_SPHERE_TESTS] = o.sphere_fetch == RT_FETCH_BVH ? o.stats[RT_STAT_BVH_TESTS] : o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
+        o.stats[RT_STAT_SPHERE_TESTS] = (o.sphere_fetch == RT_FETCH_BVH || o.sphere_fetch == RT_FETCH_BVH_GLOBAL) ? o.stats[RT_STAT_BVH_TESTS] : o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
     const std::string keep = g_error;
     cleanup();
     (void)hipSetDevice(prev_device);

@@ -160,8 +160,22 @@ void build_bvh(const float *centre_r2, const float *k, const float *radius, cons
     const int32_t n_nodes = static_cast<int32_t>(b.tree.size());
     out.n_nodes = n_nodes;
     out.nodes.resize(8 * static_cast<size_t>(n_nodes));
+    const bool compact = n_nodes <= BVH_LDS_MAX_NODES && m <= 8192;
+    if (compact) {
+        out.lds_boxes.resize(n_nodes);
+        out.lds_links.assign(8 * static_cast<size_t>(n_nodes), 0u);
+        for (int32_t i = 0; i < n_nodes; ++i) {
+            const TreeNode &t = b.tree[i];
+            uint16_t q[6];
+            for (int a = 0; a < 3; ++a) { q[a] = quant_lo(t.box.lo[a], a); q[3 + a] = quant_hi(t.box.hi[a], a); }
+            const uint32_t leaf = t.left < 0 ? (0x8000u | (static_cast<uint32_t>(t.count - 1) << 13) | static_cast<uint32_t>(t.first)) : 0u;
+            out.lds_boxes[i] = {{q[0] | (uint32_t(q[1]) << 16), q[2] | (uint32_t(q[3]) << 16), q[4] | (uint32_t(q[5]) << 16), leaf}};
+        }
+    }
+    std::vector<int> order; // tree ids in one octant's depth-first order
     for (int oct = 0; oct < 8; ++oct) {
         BvhNode *dst = out.nodes.data() + static_cast<size_t>(oct) * n_nodes;
+        order.assign(n_nodes, -1);
         int32_t next = 0;
         // iterative depth-first emission; an inner node's skip link is the index after its subtree
         struct Frame { int node; int32_t slot; int stage; };
@@ -172,6 +186,7 @@ void build_bvh(const float *centre_r2, const float *k, const float *radius, cons
             const TreeNode &t = b.tree[f.node];
             if (f.stage == 0) {
                 f.slot = next++;
+                order[f.slot] = f.node;
                 BvhNode &o = dst[f.slot];
                 for (int a = 0; a < 3; ++a) { o.lo[a] = quant_lo(t.box.lo[a], a); o.hi[a] = quant_hi(t.box.hi[a], a); }
                 if (t.left < 0) {
@@ -189,6 +204,16 @@ void build_bvh(const float *centre_r2, const float *k, const float *radius, cons
             } else {
                 dst[f.slot].link = static_cast<uint32_t>(next);
                 stack.pop_back();
+            }
+        }
+        if (compact) {
+            // the same order expressed on tree ids: slot s holds tree node order[s]; its successors are slot s+1 (hit) and its skip slot (miss)
+            uint32_t *links = out.lds_links.data() + static_cast<size_t>(oct) * n_nodes;
+            auto id_of = [&](int32_t slot) { return slot >= n_nodes ? BVH_LDS_END : static_cast<uint32_t>(order[slot]); };
+            for (int32_t s = 0; s < n_nodes; ++s) {
+                const bool is_leaf = (dst[s].link & BVH_LEAF_FLAG) != 0;
+                const uint32_t hit = id_of(s + 1), miss = is_leaf ? hit : id_of(static_cast<int32_t>(dst[s].link));
+                links[order[s]] = hit | (miss << 16);
             }
         }
     }

@@ -39,11 +39,22 @@ struct BvhSphere {
     int32_t material;
 };
 
+// Compact form for hierarchies small enough to live in LDS (BVH_LDS_MAX_NODES): one copy of the
+// boxes in tree order and, per direction octant, two 16-bit links per node.
+constexpr int BVH_LDS_MAX_NODES = 1280;      // 1280 * (16 + 8 * 4) bytes = 60 KiB of LDS per workgroup
+constexpr uint32_t BVH_LDS_END = 0xffffu;
+// {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, leaf}; leaf = 0 for an inner node,
+// otherwise 0x8000 | (count - 1) << 13 | first (a range of the leaf sphere array)
+struct BvhBoxLds { uint32_t w[4]; };
+
 struct BvhHost {
     int32_t n_nodes = 0;            // nodes per octant
     std::vector<BvhNode> nodes;     // 8 * n_nodes, octant-major; octant bit k set = direction component k negative
     std::vector<BvhSphere> spheres; // leaf order (the same for every octant)
     float origin[3] = {0, 0, 0}, step[3] = {1, 1, 1}; // the quantisation grid
+    // compact form, filled when n_nodes <= BVH_LDS_MAX_NODES and the leaf array has at most 8192 spheres:
+    std::vector<BvhBoxLds> lds_boxes;  // n_nodes, tree order (node 0 = root)
+    std::vector<uint32_t> lds_links;   // 8 * n_nodes, octant-major: (next node when the box is hit) | (next node when it is missed) << 16
     int32_t n_big = 0;
     BvhSphere big[BVH_BIG_MAX];     // spheres outside the hierarchy, ascending list index
 };

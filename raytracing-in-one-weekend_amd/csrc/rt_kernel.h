@@ -8,6 +8,7 @@ namespace rtk {
 constexpr int TILE = 8;              // a wave64 owns one 8x8-pixel tile, lane l -> (l & 7, l >> 3)
 constexpr int WAVES_PER_BLOCK = 4;   // 256-thread workgroups: four tiles share one LDS copy of the spheres
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+constexpr int BVH_LDS_BLOCK_THREADS = 512; // hierarchy in LDS: eight waves share one copy
 constexpr int GROUP = 4;             // sphere records are fetched and tested four at a time
 constexpr int SCAN_STEP = 2 * GROUP;  // spheres per iteration of the scan loop (two register sets)
 constexpr int REJECTION_CAP = 64;    // bound on the two rejection-sampling loops (P(reaching it) < 1e-20)
@@ -53,6 +54,8 @@ struct RenderParams {
     const void *bvh_spheres;
     int32_t bvh_n_nodes;
     int32_t bvh_n_big;
+    const void *bvh_lds_boxes;  // compact form staged into LDS by every workgroup (NULL: the hierarchy is too large for that)
+    const void *bvh_lds_links;
     float bvh_origin[3], bvh_step[3];
     float bvh_big[8][8];        // {cx, cy, cz, K, r*r, 1/r, index, material} (the last two as integer bits)
     // image and work

@@ -164,9 +164,11 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
 
-template <typename Real, bool FMA, int FETCH, bool QUEUE, bool BVH = false>
-__global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
-    static_assert(!BVH || (FMA && QUEUE), "the hierarchy is traversed in the throughput arithmetic only");
+// BVH: 0 = list scan; 1 = hierarchy in global memory (16-byte nodes, one order per direction octant);
+//      2 = hierarchy in LDS (boxes once, 16-bit links per octant), for hierarchies small enough
+template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0>
+__global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
+    static_assert(BVH == 0 || (FMA && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in the throughput arithmetic only");
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of SCAN_STEP
@@ -181,6 +183,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
     R4 *l_rec = reinterpret_cast<R4 *>(lds_raw);
     if (FETCH == FETCH_LDS) {
         for (int i = threadIdx.x; i < n + GROUP; i += BLOCK_THREADS) l_rec[i] = g_rec[i];
+        __syncthreads();
+    }
+    // hierarchy in LDS: n boxes of 16 bytes, then 8 * n links
+    uint4 *l_boxes = reinterpret_cast<uint4 *>(lds_raw);
+    uint32_t *l_links = reinterpret_cast<uint32_t *>(l_boxes + P.bvh_n_nodes);
+    if constexpr (BVH == 2) {
+        const uint4 *gb = static_cast<const uint4 *>(P.bvh_lds_boxes);
+        const uint32_t *gl = static_cast<const uint32_t *>(P.bvh_lds_links);
+        for (int i = threadIdx.x; i < P.bvh_n_nodes; i += BVH_LDS_BLOCK_THREADS) l_boxes[i] = gb[i];
+        for (int i = threadIdx.x; i < 8 * P.bvh_n_nodes; i += BVH_LDS_BLOCK_THREADS) l_links[i] = gl[i];
         __syncthreads();
     }
     // throughput mode: pair j = spheres 2j and 2j+1 as {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
             const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
-            if constexpr (BVH) {
+            if constexpr (BVH != 0) {
                 // Closest hit through the bounding-volume hierarchy instead of the list (the TODO at
                 // main.odin:559).  Per lane, no stack: nodes are in depth-first order for this ray's
                 // direction octant; a node whose box the segment [0, closest] meets is followed by
@@ -453,42 +465,66 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
                 for (int g = 0; g < P.bvh_n_big; ++g)
                     test_sphere(P.bvh_big[g][0], P.bvh_big[g][1], P.bvh_big[g][2], P.bvh_big[g][3], P.bvh_big[g][4], __float_as_int(P.bvh_big[g][6]));
 
-                const uint4 *__restrict__ nodes = static_cast<const uint4 *>(P.bvh_nodes) +
+                const int octant =
 #ifdef RT_DIAG_BVH_ONE_ORDER
                     0;
 #else
-                    static_cast<size_t>((rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0)) * static_cast<size_t>(P.bvh_n_nodes);
+                    (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
 #endif
                 const float4 *__restrict__ leaves = static_cast<const float4 *>(P.bvh_spheres);
                 // box corner = origin + q*step, so its slab parameter (corner - o)/d is q*A + B
                 const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
                 const float ax = P.bvh_step[0] * ix, ay = P.bvh_step[1] * iy, az = P.bvh_step[2] * iz;
                 const float bx = (P.bvh_origin[0] - ro.x) * ix, by = (P.bvh_origin[1] - ro.y) * iy, bz = (P.bvh_origin[2] - ro.z) * iz;
-                int node = 0;
-                while (node < P.bvh_n_nodes) {
-                    const uint4 nd = nodes[node]; // {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, link}
+                // does the segment [0, closest] meet the box {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16}?
+                // A NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box.
+                auto meets_box = [&](const uint32_t w0, const uint32_t w1, const uint32_t w2) -> bool {
                     ++bvh_nodes;
-#ifdef RT_DIAG_BVH
+#if defined(RT_DIAG_BVH) && !defined(RT_DIAG_BVH_LEAF)
                     if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++bvh_wave_steps; // one lane per trip of the wave
 #endif
-                    // slab test; a NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box
-                    const float tx0 = fma_rn(static_cast<float>(nd.x & 0xffffu), ax, bx), tx1 = fma_rn(static_cast<float>(nd.y >> 16), ax, bx);
-                    const float ty0 = fma_rn(static_cast<float>(nd.x >> 16), ay, by), ty1 = fma_rn(static_cast<float>(nd.z & 0xffffu), ay, by);
-                    const float tz0 = fma_rn(static_cast<float>(nd.y & 0xffffu), az, bz), tz1 = fma_rn(static_cast<float>(nd.z >> 16), az, bz);
+                    const float tx0 = fma_rn(static_cast<float>(w0 & 0xffffu), ax, bx), tx1 = fma_rn(static_cast<float>(w1 >> 16), ax, bx);
+                    const float ty0 = fma_rn(static_cast<float>(w0 >> 16), ay, by), ty1 = fma_rn(static_cast<float>(w2 & 0xffffu), ay, by);
+                    const float tz0 = fma_rn(static_cast<float>(w1 & 0xffffu), az, bz), tz1 = fma_rn(static_cast<float>(w2 >> 16), az, bz);
                     const float t_in = max_num(max_num(min_num(tx0, tx1), min_num(ty0, ty1)), max_num(min_num(tz0, tz1), 0.0f));
                     const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), closest));
-                    const bool is_leaf = (nd.w & 0x80000000u) != 0u;
-                    if (t_in <= t_out) {
-                        if (is_leaf) {
-                            const int first = static_cast<int>(nd.w & 0x0fffffffu), count = static_cast<int>((nd.w >> 28) & 7u) + 1;
-                            for (int j = first; j < first + count; ++j) {
-                                const float4 s0 = leaves[2 * j], s1 = leaves[2 * j + 1]; // {centre, K} {r*r, 1/r, index, material}
-                                test_sphere(s0.x, s0.y, s0.z, s0.w, s1.x, __float_as_int(s1.z));
-                            }
+                    return t_in <= t_out;
+                };
+                auto test_leaf = [&](const int first, const int count) {
+#ifdef RT_DIAG_BVH_LEAF
+                    if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++bvh_wave_steps; // wave-level entries into the leaf code
+#endif
+                    for (int j = first; j < first + count; ++j) {
+                        const float4 s0 = leaves[2 * j], s1 = leaves[2 * j + 1]; // {centre, K} {r*r, 1/r, index, material}
+                        test_sphere(s0.x, s0.y, s0.z, s0.w, s1.x, __float_as_int(s1.z));
+                    }
+                };
+                if constexpr (BVH == 1) {
+                    const uint4 *__restrict__ nodes = static_cast<const uint4 *>(P.bvh_nodes) + static_cast<size_t>(octant) * static_cast<size_t>(P.bvh_n_nodes);
+                    int node = 0;
+                    while (node < P.bvh_n_nodes) {
+                        const uint4 nd = nodes[node]; // box, link
+                        const bool is_leaf = (nd.w & 0x80000000u) != 0u;
+                        if (meets_box(nd.x, nd.y, nd.z)) {
+                            if (is_leaf) test_leaf(static_cast<int>(nd.w & 0x0fffffffu), static_cast<int>((nd.w >> 28) & 7u) + 1);
+                            node = node + 1;
+                        } else {
+                            node = is_leaf ? node + 1 : static_cast<int>(nd.w);
                         }
-                        node = node + 1;
-                    } else {
-                        node = is_leaf ? node + 1 : static_cast<int>(nd.w);
+                    }
+                } else {
+                    // LDS form: tree order, the successors of a node for this octant in one 32-bit word
+                    const uint32_t *links = l_links + octant * P.bvh_n_nodes;
+                    uint32_t node = P.bvh_n_nodes > 0 ? 0u : 0xffffu;
+                    while (node != 0xffffu) {
+                        const uint4 nd = l_boxes[node]; // box, leaf range
+                        const uint32_t link = links[node];
+                        if (meets_box(nd.x, nd.y, nd.z)) {
+                            if (nd.w != 0u) test_leaf(static_cast<int>(nd.w & 0x1fffu), static_cast<int>((nd.w >> 13) & 3u) + 1);
+                            node = link & 0xffffu;
+                        } else {
+                            node = link >> 16;
+                        }
                     }
                 }
             } else {
@@ -681,7 +717,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_ker
             atomicAdd(&P.stats[3], static_cast<unsigned long long>(smp));
             atomicAdd(&P.stats[4], static_cast<unsigned long long>(iters));
         }
-        if constexpr (BVH) {
+        if constexpr (BVH != 0) {
             uint32_t nb = bvh_nodes, nt = bvh_tests;
             for (int off = 32; off > 0; off >>= 1) { nb += __shfl_xor(nb, off, 64); nt += __shfl_xor(nt, off, 64); }
             if (lane == 0) {
@@ -822,7 +858,14 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
         // queue mode: as many workgroups as the chip holds at once (or fewer if the work is smaller)
         const int64_t waves_needed = static_cast<int64_t>(p.n_items);
         const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (waves_needed + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
-        if (fetch == FETCH_BVH) launch_k(render_kernel<float, true, FETCH_SCALAR, true, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        if (fetch == FETCH_BVH && p.bvh_lds_boxes != nullptr) {
+            // the hierarchy fits LDS: 48 bytes per node and workgroup, which also bounds how many workgroups a CU holds
+            const size_t lds_bytes = static_cast<size_t>(p.bvh_n_nodes) * 48;
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2048 / BVH_LDS_BLOCK_THREADS, (160 * 1024) / std::max<size_t>(lds_bytes, 1))));
+            const int fit = std::max(1, resident_blocks / 8 * per_cu);
+            const int wanted = static_cast<int>((waves_needed + BVH_LDS_BLOCK_THREADS / 64 - 1) / (BVH_LDS_BLOCK_THREADS / 64));
+            hipLaunchKernelGGL((render_kernel<float, true, FETCH_SCALAR, true, 2>), dim3(std::max(1, std::min(wanted, fit))), dim3(BVH_LDS_BLOCK_THREADS, 1, 1), lds_bytes, stream, p);
+        } else if (fetch == FETCH_BVH) launch_k(render_kernel<float, true, FETCH_SCALAR, true, 1>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
         else if (lds) launch_k(render_kernel<float, true, FETCH_LDS, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
         else launch_k(render_kernel<float, true, FETCH_SCALAR, true>, dim3(grid), fetch, p.n_spheres, sizeof(float4), stream, p);
         break;

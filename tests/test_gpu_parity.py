@@ -327,8 +327,11 @@ def test_bvh_equals_list_scan(rt, oracle, name, width, spp):
         cs, cam, sph, mat = scene(rt, name, width, spp)
     w, h = cs.image_width, cs.image_height
     a, lin_a, st_a = gpu_render(rt, cs, cam, sph, mat, seed=12)
-    b, lin_b, st_b = gpu_render(rt, cs, cam, sph, mat, seed=12, sphere_fetch=rt.FETCH_BVH)
+    b, lin_b, st_b = gpu_render(rt, cs, cam, sph, mat, seed=12, sphere_fetch=rt.FETCH_BVH)          # in LDS when it fits
+    c, lin_c, st_c = gpu_render(rt, cs, cam, sph, mat, seed=12, sphere_fetch=rt.FETCH_BVH_GLOBAL)   # always in global memory
     assert np.array_equal(a, b) and np.array_equal(lin_a, lin_b)
+    assert np.array_equal(a, c) and np.array_equal(lin_a, lin_c)
+    assert [int(v) for v in st_b[[0, 5, 6]]] == [int(v) for v in st_c[[0, 5, 6]]]  # the same boxes and spheres either way
     assert int(st_a[rt.STAT_SEGMENTS]) == int(st_b[rt.STAT_SEGMENTS])
     assert int(st_b[rt.STAT_SPHERE_TESTS]) == int(st_b[rt.STAT_BVH_TESTS]) > 0
     if len(sph) > 100:
