@@ -382,3 +382,29 @@ def test_metal_fresnel_material_type(rt, oracle, precision):
     bad["type"][0] = 4
     with pytest.raises(rt.RtError):
         gpu_render(rt, cs, cam, sph, bad, seed=6)
+
+
+def test_concurrent_calls_from_host_threads(rt):
+    """The reference calls render_region from pool threads on disjoint rects (main.odin:609, :673-679);
+    the one-shot entry point must stay correct when several host threads call it at once."""
+    import threading
+    cs, cam, sph, mat = scene(rt, "dev", 96, 6)
+    w, h = cs.image_width, cs.image_height
+    whole, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=31)
+    image = np.full((h, w, 3), -7.0)
+    rects = [(0, 0, 40, 30), (40, 0, w, 30), (0, 30, 51, h), (51, 30, w, h)]
+    errors = []
+
+    def work(rect):
+        try:
+            rt.render_region(image, rect, cam, sph, mat, seed=31)
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in rects]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    assert np.array_equal(image, whole)  # disjoint rects tile the image; the paths do not depend on the rect
