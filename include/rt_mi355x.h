@@ -125,7 +125,9 @@ typedef struct {
     int32_t sphere_fetch;  /* RT_FETCH_*                                                       */
     int32_t device;        /* HIP device ordinal, or -1 for the calling thread's current one  */
     int32_t device_count;  /* rt_render_region only: spread 8-row strips over this many GPUs
-                              starting at `device` (0 and 1 both mean one GPU)                */
+                              starting at `device` (0 and 1 both mean one GPU).  With
+                              RT_MI355X_WRAP_DEVICES=1 in the environment the ordinals wrap
+                              around the visible GPUs (a testing aid for boxes with fewer)   */
     int32_t sample_chunks; /* split samples_per_pixel over this many waves per tile; 0 = auto */
     rt_v3 *linear_out;     /* optional, width*height: pre-gamma sample means of region pixels  */
     uint64_t *stats;       /* optional, RT_STATS_COUNT counters for this call                  */

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -504,7 +505,13 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     int first = o.device;
     if (first < 0) HIP_TRY(hipGetDevice(&first));
     const int count = std::max(1, o.device_count);
-    if (first >= n_dev || first + count > n_dev) return fail(RT_ERR_DEVICE, "devices [%d, %d) requested, %d visible", first, first + count, n_dev);
+    // RT_MI355X_WRAP_DEVICES=1 maps device ordinals modulo the visible count, so that the strip logic of
+    // device_count > 1 can be exercised on a machine with fewer GPUs (every "device" then has its own stream,
+    // world and buffers on a shared GPU)
+    const char *wrap_env = std::getenv("RT_MI355X_WRAP_DEVICES");
+    const bool wrap = wrap_env != nullptr && wrap_env[0] == '1' && n_dev > 0;
+    if (!wrap && (first >= n_dev || first + count > n_dev)) return fail(RT_ERR_DEVICE, "devices [%d, %d) requested, %d visible", first, first + count, n_dev);
+    auto ordinal = [&](int g) { return wrap ? (first + g) % n_dev : first + g; };
 
     uint64_t seed = o.seed;
     if (o.rng_mode == RT_RNG_STOCHASTIC) {
@@ -535,12 +542,18 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     int prev_device = 0;
     HIP_TRY(hipGetDevice(&prev_device));
     std::vector<std::unique_lock<std::mutex>> locks;
-    for (int g = 0; g < count; ++g) locks.emplace_back(device_mutex(first + g));
+    {
+        std::vector<int> used;
+        for (int g = 0; g < count; ++g) used.push_back(ordinal(g));
+        std::sort(used.begin(), used.end());
+        used.erase(std::unique(used.begin(), used.end()), used.end());
+        for (int dev : used) locks.emplace_back(device_mutex(dev)); // ascending order: no lock-order inversion between calls
+    }
 
     // launch everything on every device, then collect
     for (int g = 0; g < count && result == RT_OK; ++g) {
         PerDevice &d = devs[g];
-        d.device = first + g;
+        d.device = ordinal(g);
         hipError_t e = hipSetDevice(d.device);
         if (e == hipSuccess) e = hipStreamCreate(&d.stream);
         if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * accum_size(o.precision));

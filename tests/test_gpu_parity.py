@@ -408,3 +408,24 @@ def test_concurrent_calls_from_host_threads(rt):
         t.join()
     assert not errors
     assert np.array_equal(image, whole)  # disjoint rects tile the image; the paths do not depend on the rect
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+def test_in_process_multi_device_strips(rt, count, monkeypatch):
+    """rt_render_region with device_count > 1 (8-row strips dealt round-robin over the devices, each with
+    its own world, stream and buffers, strips copied back one by one).  On a one-GPU box the library maps
+    the ordinals onto the GPUs there are (RT_MI355X_WRAP_DEVICES=1); the image and the counters must be
+    those of the single-device call."""
+    monkeypatch.setenv("RT_MI355X_WRAP_DEVICES", "1")
+    cs, cam, sph, mat = scene(rt, "dev", 100, 5)   # 100x56: ragged last strip, ragged last tile column
+    w, h = cs.image_width, cs.image_height
+    one, lin_one, st_one = gpu_render(rt, cs, cam, sph, mat, seed=14)
+    many, lin_many, st_many = gpu_render(rt, cs, cam, sph, mat, seed=14, device=0, device_count=count)
+    assert np.array_equal(one, many) and np.array_equal(lin_one, lin_many)
+    assert int(st_one[0]) == int(st_many[0]) and int(st_one[3]) == int(st_many[3])
+    region = (7, 9, 93, 50)
+    a, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=14, region=region)
+    b, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=14, region=region, device=0, device_count=count)
+    assert np.array_equal(a, b)
+    text = rt.render_ppm(w, h, cam, sph, mat, seed=14, device=0, device_count=count)
+    assert text == rt.serialize_ppm(one)
