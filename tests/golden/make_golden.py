@@ -4,7 +4,10 @@
 rng_kat.json            counter-RNG known answers, computed by the pure-Python restatement (tests/pyref.py)
 render_<scene>_f64.npz  32x18, 4 spp gamma image + linear means of the two small benchmark configurations ("two": two lambertian spheres; "dev": the three-material scene),
                         computed by tests/pyref.py in IEEE f64 -- independent of the C++ oracle and of the GPU
-render_<scene>_f32.npz  the same renders in the two f32 arithmetics, computed by the C++ oracle (regression pins)
+render_<scene>_f32.npz  the same renders in the two f32 arithmetics: the throughput arithmetic ("fma": image, linear means
+                        and Q32.32 sums) computed by tests/pyref32.py -- numpy float32 operations and exact rational
+                        fused multiply-adds, independent of the C++ oracle and of the GPU; the literal f32 mode
+                        ("literal") computed by the C++ oracle (a regression pin)
 intersection_kat.json   ray_sphere_intersection cases with closed-form answers
 No reference source or reference output is involved: the reference ships no vectors for this path.
 """
@@ -20,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pyref  # noqa: E402
+import pyref32  # noqa: E402
 import oracle_lib  # noqa: E402
 
 rt = importlib.import_module("raytracing-in-one-weekend_amd")
@@ -57,11 +61,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"render_{name}_f64.npz"), image=image, linear=linear, segments=np.int64(seg),
                             seed=np.uint64(SEED), spp=np.int64(SPP), width=np.int64(w), height=np.int64(h))
         out = {}
-        for label, precision in (("fma", rt.PRECISION_F32), ("literal", rt.PRECISION_F32_LITERAL)):
-            r = o.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=SEED)
-            out[f"image_{label}"] = r["image"]
-            out[f"linear_{label}"] = r["linear"]
-            out[f"segments_{label}"] = np.int64(r["stats"][0])
+        img32, sums32, seg32 = pyref32.render_region(w, h, (0, 0, w, h), cam_dict(cam), spl, ml, SEED)
+        out["image_fma"] = np.array([[img32[(u, v)] for u in range(w)] for v in range(h)])
+        out["accum_fma"] = np.array([[sums32[(u, v)] for u in range(w)] for v in range(h)], dtype=np.uint64)
+        out["linear_fma"] = out["accum_fma"].astype(np.float64) * (1.0 / 4294967296.0) * (1.0 / SPP)
+        out["segments_fma"] = np.int64(seg32)
+        r = o.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F32_LITERAL, seed=SEED)
+        out["image_literal"] = r["image"]
+        out["linear_literal"] = r["linear"]
+        out["segments_literal"] = np.int64(r["stats"][0])
         np.savez_compressed(os.path.join(HERE, f"render_{name}_f32.npz"), seed=np.uint64(SEED), spp=np.int64(SPP), **out)
         print(name, w, h, "segments", seg)
 

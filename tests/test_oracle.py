@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import pyref
+import pyref32
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -203,6 +204,38 @@ def test_live_pyref_cross_check_with_region_and_dof(rt, oracle):
     outside = np.ones((h, w), dtype=bool)
     outside[region[1]:region[3], region[0]:region[2]] = False
     assert np.all(r["image"][outside] == 0.0)
+
+
+def test_f32_throughput_arithmetic_against_python_statement(rt, oracle):
+    """The oracle's f32 throughput mode against tests/pyref32.py (numpy float32 operations, exact rational
+    fused multiply-adds, written from the description of the arithmetic): image, Q32.32 sums and segment
+    count, on a ragged region of the three-material scene with the gold switched to the Fresnel variant."""
+    cs, sph, mat = rt.build_dev_scene(20)
+    cs.samples_per_pixel = 3
+    mat = mat.copy()
+    mat["type"][4] = 3
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    region = (3, 1, 17, 10)
+    spl, ml = as_lists(sph, mat)
+    img, sums, seg = pyref32.render_region(w, h, region, cam_dict(cam), spl, ml, 91)
+    r = oracle.render_region(w, h, region, cam, sph, mat, precision=0, seed=91)
+    for (u, v), c in img.items():
+        assert tuple(r["image"][v, u]) == c
+        assert tuple(int(x) for x in r["accum"][v, u]) == sums[(u, v)]
+    assert int(r["stats"][0]) == seg
+
+
+def test_exact_fma_of_the_python_statement():
+    """pyref32.fma rounds once: cases where rounding the f64 result of a*b+c to f32 would round twice"""
+    F = np.float32
+    # a*b + c with a*b exactly representable in f64 and the sum needing one rounding to f32
+    assert pyref32.fma(F(1.0), F(1.0), F(2.0 ** -24)) == F(1.0)                       # tie: to even
+    assert pyref32.fma(F(1.0), F(1.0 + 2.0 ** -23), F(2.0 ** -24)) == F(1.0 + 2.0 ** -22)  # tie: to even, upwards
+    assert pyref32.fma(F(3.0), F(1.0 / 3.0), F(-1.0)) == F(np.float64(F(3.0)) * np.float64(F(1.0 / 3.0)) - 1.0)  # exact small result
+    x = F(1.0 + 2.0 ** -23)
+    assert pyref32.fma(x, x, F(-1.0)) == F(2.0 ** -22 + 2.0 ** -46)                   # the low product bits survive the cancellation
+    assert np.signbit(pyref32.fma(F(0.0), F(-1.0), F(-0.0))) and not np.signbit(pyref32.fma(F(1.0), F(1.0), F(-1.0)))
 
 
 def test_empty_world_is_the_sky_gradient(rt, oracle):
