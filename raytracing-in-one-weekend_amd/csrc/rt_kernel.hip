@@ -12,23 +12,29 @@
 //   traced what.  Lanes idle only when the whole queue is empty.
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
-// Closest-hit scan
-//   The sphere index is wave-uniform: records {cx, cy, cz, r*r} come four at a time through the
-//   scalar cache into SGPRs (or from LDS), the next four being fetched while these are tested.
-//   Per sphere a lane spends 3 fused multiply-adds for h = d.c - d.o, 4 for
-//   a*c = a(|c|^2 - r^2) - 2a c.o + a|o|^2 and one for the discriminant h*h - a*c
+// Closest-hit scan (throughput mode)
+//   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1},
+//   K = |c|^2 - r^2, come through the scalar cache into SGPRs, the next group of four spheres
+//   being fetched while this one is tested.  Per sphere a lane spends 3 fused multiply-adds for
+//   h = d.c - d.o, 4 for a*c = a*K - 2a c.o + a|o|^2 and one for the discriminant h*h - a*c
 //   (main.odin:245-249 with the squares expanded and the per-ray and per-sphere parts
 //   hoisted), all as packed instructions on two spheres at once; a group of four spheres
-//   shares one compare.  Only when some lane's line meets the sphere does the
-//   wave leave the straight-line code; such a lane parks the candidate (h, disc, index) in
-//   registers and the square root / divisions / range tests of main.odin:252-261 run later, for
-//   all parked lanes at once, when a lane needs its slot again or the scan ends.  A lane's
-//   candidates are still resolved in sphere order with the shrinking t_max of
-//   main.odin:541-545, so results equal the straight loop's.
+//   shares one compare.  Only when some lane's line meets a sphere of the group does the wave
+//   leave the straight-line code; such a lane parks the sphere's index, and the roots -- from
+//   the centre-to-line vector, whose rounding scales with the sphere and not with its distance
+//   -- and the range tests of main.odin:250-261 are evaluated later, for all parked lanes at
+//   once, when a lane needs its slot again or the scan ends.  A lane's candidates are still
+//   resolved in sphere order with the shrinking t_max of main.odin:541-545, so results equal
+//   the straight loop's.  The sphere a scattered segment starts on is tested before the scan
+//   with c = 0 (in f64 the reference sees |c| ~ 1e-15 there; in f32 the rounding of c would
+//   produce spurious self-intersections).  BVH variants replace the list by a per-lane,
+//   stackless traversal of a bounding-volume hierarchy with the same per-sphere test.
+//   Literal modes: records {cx, cy, cz, r*r}, the reference's expressions as written.
 // Arithmetic
-//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma() calls of
-//   the F32_FMA scan.  Division and square root are IEEE correctly rounded.  Everything outside
-//   the scan follows the reference's operation order.
+//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma calls of
+//   the throughput mode.  Division and square root are IEEE correctly rounded.  In throughput
+//   mode a vector is divided by a scalar as one reciprocal and three products; everything else
+//   follows the reference's operation order.
 #include "rt_kernel.h"
 #include <type_traits>
 
@@ -345,7 +351,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         int pend = -1;
 
         auto resolve = [&]() {
-            RT_DIAG_COUNT(diag_resolves);
+#ifdef RT_DIAG_COUNTERS
+            if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_resolves; // one lane per execution by the wave
+#endif
             if constexpr (FMA) {
                 // Throughput arithmetic: the scan's discriminant h^2 - a*c is the difference of two
                 // numbers of size a*|centre - o|^2 and only selects candidates.  A candidate's roots
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 #endif
         }
 #ifdef RT_DIAG_COUNTERS
-        // entries: per wave (uniform, take lane 0's); resolves: wave-level calls (max over lanes approximates); parked: lane total
+        // entries: per wave (uniform, lane 0 holds it); resolves: executions by the wave (counted by one lane each); parked: lane total
         uint32_t par = diag_parked, res = diag_resolves;
         for (int off = 32; off > 0; off >>= 1) { par += __shfl_xor(par, off, 64); res += __shfl_xor(res, off, 64); }
         if (lane == 0) {

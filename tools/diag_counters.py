@@ -10,4 +10,4 @@ world.render_accumulate(cam, w, h, acc.data_ptr(), seed=1, d_stats=st.data_ptr()
 s = st.cpu().numpy()
 it = s[4]; print("segments", s[0], "wave iterations", it, "groups/iter", 488/4)
 print("group entries per iteration %.1f (%.1f%% of groups)" % (s[5]/it, 100*s[5]/it/122))
-print("lane-resolves per iteration %.2f; parked candidates per lane-segment %.3f" % (s[6]/it, s[7]/s[0]))
+print("wave-level resolve executions per iteration %.2f; parked candidates per lane-segment %.3f" % (s[6]/it, s[7]/s[0]))
