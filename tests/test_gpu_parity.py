@@ -429,3 +429,63 @@ def test_in_process_multi_device_strips(rt, count, monkeypatch):
     assert np.array_equal(a, b)
     text = rt.render_ppm(w, h, cam, sph, mat, seed=14, device=0, device_count=count)
     assert text == rt.serialize_ppm(one)
+
+
+def _random_world(rt, rng, n):
+    """spheres of mixed sizes -- overlapping, nested, coincident, one huge -- and all four material types"""
+    mat = np.zeros(6, dtype=rt.MATERIAL_DTYPE)
+    mat["type"] = [0, 1, 2, 2, 3, 0]
+    mat["albedo"] = rng.uniform(0.1, 0.95, size=(6, 3))
+    mat["param1"] = [0.0, rng.uniform(0.0, 1.0), 1.5, 1.0 / 1.5, rng.uniform(0.0, 0.4), 0.0]
+    sph = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+    sph["center"] = rng.uniform(-3.0, 3.0, size=(n, 3))
+    sph["radius"] = rng.choice([0.05, 0.3, 0.8, 1.5], size=n) * rng.uniform(0.7, 1.3, size=n)
+    sph["material_index"] = rng.integers(0, 6, size=n)
+    if n >= 3:
+        sph["center"][1] = sph["center"][0]                      # concentric pair (glass shell / bubble)
+        sph["radius"][1] = 0.8 * sph["radius"][0]
+        sph["material_index"][0], sph["material_index"][1] = 2, 3
+        sph[2] = sph[0]                                           # an exact duplicate: ties go to the lower index
+    if n >= 5:
+        sph["center"][4] = (0.0, -200.0, 0.0)                     # a huge sphere under everything
+        sph["radius"][4] = 197.0
+    return sph, mat
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_worlds_against_oracle(rt, oracle, case):
+    """Random worlds, cameras, regions, sample counts and bounce limits: GPU (three precisions, plus the
+    hierarchy in LDS and in global memory for f32) against the oracle, bitwise."""
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([1, 2, 3, 5, 9, 17, 40]))
+    sph, mat = _random_world(rt, rng, n)
+    cs, _, _ = rt.build_dev_scene(int(rng.choice([24, 33, 48])))
+    eye = rng.uniform(-6.0, 6.0, size=3)
+    cs.position = rt.V3(*eye)
+    right, up, fwd = rt.lookat(tuple(eye), tuple(rng.uniform(-1.0, 1.0, size=3)), (0.0, 1.0, 0.0))
+    cs.right, cs.up, cs.forward = rt.V3(*right), rt.V3(*up), rt.V3(*fwd)
+    cs.vfov = float(rng.uniform(0.05, 0.3))
+    cs.focus_distance = float(rng.uniform(1.0, 8.0))
+    cs.depth_of_field_angle = float(rng.choice([0.0, 0.01, 0.05]))
+    cs.samples_per_pixel = int(rng.integers(1, 6))
+    cs.max_ray_bounces = int(rng.choice([0, 1, 4, 12, 50]))
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+    region = (x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1)))
+    seed = int(rng.integers(0, 2 ** 63))
+    for precision in (0, 1, 2):
+        ref = oracle.render_region(w, h, region, cam, sph, mat, precision=precision, seed=seed)
+        image, linear, stats = gpu_render(rt, cs, cam, sph, mat, region=region, seed=seed, precision=precision, sample_chunks=1)
+        sl = (slice(region[1], region[3]), slice(region[0], region[2]))
+        assert np.array_equal(image[sl], ref["image"][sl]), (case, precision)
+        assert np.array_equal(linear[sl], ref["linear"][sl]), (case, precision)
+        assert int(stats[0]) == int(ref["stats"][0]), (case, precision)
+        outside = np.ones((h, w), dtype=bool)
+        outside[sl] = False
+        assert np.all(image[outside] == -7.0)
+        if precision == 0:
+            for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL, rt.FETCH_LDS):
+                other, _, st = gpu_render(rt, cs, cam, sph, mat, region=region, seed=seed, sphere_fetch=fetch)
+                assert np.array_equal(other[sl], ref["image"][sl]), (case, fetch)
+                assert int(st[0]) == int(ref["stats"][0]), (case, fetch)
