@@ -351,6 +351,9 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     if (fetch == RT_FETCH_BVH && !world->bvh_built) {
         rtk::BvhHost &bvh = world->bvh_host;
         rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
+        // a previous attempt may have failed half way: start from nothing
+        for (void **buf : {&world->bvh_nodes, &world->bvh_spheres, &world->bvh_lds_boxes, &world->bvh_lds_links})
+            if (*buf) { (void)hipFree(*buf); *buf = nullptr; }
         HIP_TRY(hipMalloc(&world->bvh_nodes, std::max<size_t>(64, bvh.nodes.size() * sizeof(rtk::BvhNode))));
         HIP_TRY(hipMalloc(&world->bvh_spheres, std::max<size_t>(64, bvh.spheres.size() * sizeof(rtk::BvhSphere))));
         if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
