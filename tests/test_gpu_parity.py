@@ -489,3 +489,36 @@ def test_random_worlds_against_oracle(rt, oracle, case):
                 other, _, st = gpu_render(rt, cs, cam, sph, mat, region=region, seed=seed, sphere_fetch=fetch)
                 assert np.array_equal(other[sl], ref["image"][sl]), (case, fetch)
                 assert int(st[0]) == int(ref["stats"][0]), (case, fetch)
+
+
+def test_extreme_shapes(rt, oracle):
+    """one-pixel images, one-pixel regions, one sample, sphere counts around the scan's padding (multiples of 8)
+    and a few thousand spheres: GPU f32 (list scan, hierarchy) against the oracle."""
+    rng = np.random.default_rng(77)
+    for n in (7, 8, 9, 15, 16, 17, 2051):
+        sph, mat = _random_world(rt, rng, n)
+        cs, _, _ = rt.build_dev_scene(16)
+        cs.samples_per_pixel = 2
+        cs.max_ray_bounces = 6
+        cam = rt.calculate_camera_render_data(cs)
+        w, h = cs.image_width, cs.image_height
+        ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=n, threads=8)
+        for fetch in (rt.FETCH_AUTO, rt.FETCH_BVH):
+            image, _, stats = gpu_render(rt, cs, cam, sph, mat, seed=n, sphere_fetch=fetch)
+            assert np.array_equal(image, ref["image"]), (n, fetch)
+            assert int(stats[0]) == int(ref["stats"][0])
+    # a 1x1 image and a 1x1 region of a larger one, one sample
+    cs, _, _ = rt.build_dev_scene(16)
+    sph, mat = rt.build_dev_scene(16)[1:]
+    cs.image_size_x, cs.image_size_y, cs.samples_per_pixel = 1.0, 1.0, 1
+    cam = rt.calculate_camera_render_data(cs)
+    ref = oracle.render_region(1, 1, (0, 0, 1, 1), cam, sph, mat, precision=0, seed=5)
+    image = np.zeros((1, 1, 3))
+    rt.render_region(image, (0, 0, 1, 1), cam, sph, mat, seed=5)
+    assert np.array_equal(image, ref["image"])
+    cs, cam, sph, mat = scene(rt, "dev", 40, 1)
+    w, h = cs.image_width, cs.image_height
+    ref = oracle.render_region(w, h, (39, 21, 40, 22), cam, sph, mat, precision=0, seed=5)
+    image, _, stats = gpu_render(rt, cs, cam, sph, mat, region=(39, 21, 40, 22), seed=5)
+    assert np.array_equal(image[21, 39], ref["image"][21, 39]) and int(stats[rt.STAT_SAMPLES]) == 1
+    assert np.count_nonzero(image != -7.0) == 3
