@@ -2,7 +2,10 @@
 // through the C ABI -- build a scene, compute the camera, render, print a P3 PPM to stdout --
 // with the scene, size, sample count and seed selectable at run time.
 //   rt_cli [--scene dev|two|final|stress] [--width W] [--spp N] [--depth D] [--seed S]
-//          [--gpus G] [--precision f32|f64|f32-literal] [--stochastic] [--stats] [--host-ppm] > out.ppm
+//          [--gpus G] [--precision f32|f64|f32-literal] [--stochastic] [--stats] [--host-ppm] [--rounds N] > out.ppm
+// --rounds N is bench_materials of the reference (main_test.odin:8-46, :72-81): N renders of the scene through
+// the one-shot entry point, the last image to stdout, and the reference's statistics line to stderr (its
+// "bytes" are pixels, main_test.odin:24).
 // The PPM text is formatted on the GPU (rt_render_ppm); --host-ppm takes the reference's route
 // instead: the f64 image comes back and rt_serialize_ppm formats it on the host.
 #include <chrono>
@@ -19,6 +22,7 @@ int main(int argc, char **argv) {
     int64_t width = 0, spp = 0, depth = -1;
     uint64_t seed = 1;
     int gpus = 1;
+    long long rounds = 0;
     bool stochastic = false, want_stats = false, host_ppm = false;
     for (int i = 1; i < argc; ++i) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", argv[i]); std::exit(2); } return argv[++i]; };
@@ -32,6 +36,7 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--stochastic")) stochastic = true;
         else if (!std::strcmp(argv[i], "--stats")) want_stats = true;
         else if (!std::strcmp(argv[i], "--host-ppm")) host_ppm = true;
+        else if (!std::strcmp(argv[i], "--rounds")) rounds = std::atoll(next());
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     rt_camera_settings settings;
@@ -62,6 +67,25 @@ int main(int argc, char **argv) {
     opts.stats = stats;
     std::fprintf(stderr, "%s: %s scene, %lld spheres, %lldx%lld, %lld spp, depth %lld, %d GPU(s)\n", rt_version(), scene.c_str(), (long long)ns,
                  (long long)w, (long long)h, (long long)settings.samples_per_pixel, (long long)settings.max_ray_bounces, gpus);
+    if (rounds > 0) {
+        std::vector<rt_v3> image(static_cast<size_t>(w * h));
+        const auto b0 = std::chrono::steady_clock::now();
+        for (long long round = 1; round <= rounds; ++round) {
+            std::fprintf(stderr, "\rRound %lld/%lld", round, rounds);
+            rc = rt_render_tiled(image.data(), w, h, &cam, spheres.data(), ns, materials.data(), nm, &opts);
+            if (rc != RT_OK) { std::fprintf(stderr, "\nrt_render_tiled failed (%d): %s\n", rc, rt_last_error()); return 1; }
+        }
+        const double ns_total = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - b0).count();
+        std::fprintf(stderr, "\rDone.        \n");
+        const int64_t size = rt_serialize_ppm(image.data(), w, h, nullptr, 0);
+        std::vector<char> text(static_cast<size_t>(size));
+        rt_serialize_ppm(image.data(), w, h, text.data(), size);
+        std::fwrite(text.data(), 1, text.size(), stdout);
+        const double processed = double(rounds) * double(w * h); // options.bytes = len(image.data): pixels
+        std::fprintf(stderr, "[%s] %lld rounds, %.0f bytes processed in %.0f ns, %.2f rounds/s, %.2f MiB/s\n", scene.c_str(), rounds, processed, ns_total,
+                     double(rounds) / (ns_total * 1e-9), processed / (ns_total * 1e-9) / (1024.0 * 1024.0));
+        return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t need = rt_serialize_ppm(nullptr, w, h, nullptr, 0);
     std::vector<char> ppm(static_cast<size_t>(need));
