@@ -522,3 +522,34 @@ def test_extreme_shapes(rt, oracle):
     image, _, stats = gpu_render(rt, cs, cam, sph, mat, region=(39, 21, 40, 22), seed=5)
     assert np.array_equal(image[21, 39], ref["image"][21, 39]) and int(stats[rt.STAT_SAMPLES]) == 1
     assert np.count_nonzero(image != -7.0) == 3
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(monkeypatch, capsys):
+    """bench.py at a small size (run in this process: no child is started from a process that holds the GPU):
+    exactly one JSON line on stdout carrying the fields the driver reads."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8", "--cpu-seconds", "0.5", "--verify"])
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    bench.main()
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and d["verified"] is True
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] < 1.0 and d["value"] > 0
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
