@@ -92,6 +92,15 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
                                       there in f64; its f32 rounding would give spurious self-intersections)   */
 #define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
 #define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
+#define RT_PRECISION_MIXED 3       /* the image of RT_PRECISION_F64 (with one sample chunk: f64, literal order,
+                                      colours summed in sample order, main.odin:575) bit for bit, traced faster:
+                                      the f32 scan of RT_PRECISION_F32 runs on the f64 ray rounded to f32 as a
+                                      conservative filter -- a sphere is skipped only when its discriminant
+                                      (main.odin:249) is negative by more than the f32 rounding can explain --
+                                      and every sphere it keeps goes through ray_sphere_intersection as written
+                                      (main.odin:245-261) in f64; hit record, scattering and colour are f64.
+                                      Worlds outside 2^-20 <= |r|, |c| + |r| <= 2^20 are traced by the
+                                      RT_PRECISION_F64 kernel instead (same image).  RT_FETCH_AUTO / _SCALAR.    */
 
 /* how the closest hit (main.odin:536-546) is found */
 #define RT_FETCH_AUTO 0   /* = RT_FETCH_SCALAR                                                     */
@@ -199,6 +208,10 @@ int32_t rt_world_destroy(rt_world *world);
  * d_accum is a device buffer of width*height*3 elements indexed
  * [(u + v*width)*3 + channel]; the call overwrites the entries of its pixels
  * with the SUM of its samples' colours.  Element type by precision:
+ *   RT_PRECISION_MIXED       double, summed in sample order whatever sample_chunks
+ *                            says (the colours of up to RT_MI355X_STAGING_MIB -- default
+ *                            12288 -- MiB worth of samples, 24 bytes each, are staged in a
+ *                            buffer the world owns and added by a second kernel);
  *   RT_PRECISION_F32         uint64_t, Q32.32 fixed point (each f32 sample colour is
  *                            truncated to 2^-32 and added exactly, so sums over any
  *                            split of the samples -- chunks, calls, GPUs -- are equal);
@@ -210,6 +223,13 @@ int32_t rt_world_destroy(rt_world *world);
  * asynchronous with respect to the host.  Because the RNG is keyed by the
  * global pixel index and the global sample index, any partition of pixels or
  * samples over calls, streams or GPUs traces exactly the same paths.
+ * Calls on one world may be in flight on several streams at once: every call
+ * has its own work-queue head and timing events (a ring of 8; the ninth call
+ * first waits on the host for the first to end), and calls that need the
+ * world's scratch buffer (RT_PRECISION_F64 / _F32_LITERAL with more than one
+ * sample chunk, RT_PRECISION_MIXED) are ordered one after the other on the
+ * device.  Two calls that write the same d_accum entries race, as any two
+ * writers would.
  */
 int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam,
                              int64_t width, int64_t height, rt_rect region,
@@ -248,6 +268,7 @@ int32_t rt_finalize_ppm(rt_world *world, const void *d_accum, int32_t precision,
 /* device time in ns of the render kernels launched for `world` by the last
  * rt_render_accumulate on it (blocks until they finish); <0 on error */
 int64_t rt_world_last_kernel_ns(rt_world *world);
+
 
 /* ---- host-side helpers the callers of the path use ------------------------ */
 

@@ -28,6 +28,12 @@
  *                              a scalar as one reciprocal and three products, and sample
  *                              colours are summed exactly in Q32.32 with an f64 mean and
  *                              square root -- the arithmetic of the GPU throughput kernel.
+ * RT_PRECISION_MIXED         : Real = double, FMA = false, with the GPU mixed mode's f32 filter
+ *                              (mixed_filter below) in front of every ray/sphere test: a sphere
+ *                              the filter drops is not tested.  The filter is meant to be
+ *                              conservative, so the image must be that of RT_PRECISION_F64; the
+ *                              run also evaluates the dropped spheres and counts every one that
+ *                              main.odin:240-263 would have reported as hit (stats[6], must be 0).
  */
 #include <algorithm>
 #include <atomic>
@@ -265,6 +271,49 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
     return root;
 }
 
+/* The candidate filter of the GPU mixed mode: stage 1 of ray_sphere_intersection_expanded run on
+ * the f64 ray rounded to f32, with an error margin.  With u = 2^-24 and S = |center| + |o| + r the
+ * f32 discriminant differs from the f64 one of main.odin:249 by at most 34 u a S^2 (8 from rounding
+ * d, o, center, r to f32; 12 from h: three fused roundings plus the plain dot product d.o, doubled
+ * by squaring; 12 from a*c; 2 from the last fused operation), and S^2 <= 3(|center|^2 + r^2 +
+ * |o|^2).  So a*c is lowered by 2^-17 a (|center|^2 + r^2 + |o|^2) = 42.7 u a S^2: the sphere's
+ * share sits in its constant Km = K - 2^-17 (|center|^2 + r^2) (rounded down), the ray's share in
+ * aoo = a|o|^2 (1 - 2^-17).  A sphere is kept unless the lowered discriminant is negative; of the
+ * kept ones those with h < -behind and a*c > 0 (certainly behind an origin certainly outside) are
+ * dropped as well, behind = 2^-20 |d| (reach + |o|) >= 8 u |d| S bounding the error of h.  The bound
+ * needs normal f32 numbers throughout: spheres with 2^-20 <= |r| and |center| + |r| <= 2^20 (else
+ * the filter is not used at all), rays with 2^-40 <= a <= 2^40 and |o|^2 <= 2^40 (else the ray keeps
+ * every sphere). */
+struct filter_ray { expanded_ray e; float behind; bool in_range; };
+inline float sphere_constant_lowered(float cx, float cy, float cz, float radius) {
+    const double c2 = static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz, r2 = static_cast<double>(radius) * radius;
+    const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 131072.0);
+    float km = static_cast<float>(lowered);
+    if (static_cast<double>(km) > lowered) km = std::nextafterf(km, -INFINITY);
+    return km;
+}
+inline filter_ray make_filter_ray(const ray_t<double> &r, float reach) {
+    filter_ray f;
+    ray_t<float> rf{{static_cast<float>(r.origin.x), static_cast<float>(r.origin.y), static_cast<float>(r.origin.z)},
+                    {static_cast<float>(r.direction.x), static_cast<float>(r.direction.y), static_cast<float>(r.direction.z)}};
+    f.e = expand_ray(rf);
+    const float o_o = dot(rf.origin, rf.origin);
+    f.e.aoo = f.e.aoo * (1.0f - 7.62939453125e-06f);
+    f.behind = 9.5367431640625e-07f * std::sqrt(f.e.a) * (reach + std::sqrt(o_o));
+    f.in_range = (f.e.a >= 9.094947017729282e-13f) && (f.e.a <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f);
+    return f;
+}
+inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Km) {
+    if (!f.in_range) return true;
+    const expanded_ray &e = f.e;
+    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
+    const float m = std::fmaf(Km, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
+    const float disc = std::fmaf(h, h, -m);
+    if (disc < 0) return false;
+    if (h < -f.behind && m > 0) return false;
+    return true;
+}
+
 /* Throughput arithmetic, the sphere a scattered segment starts on.  Its origin is the hit point of
  * the previous segment, so c = |center - o|^2 - r^2 is zero up to the rounding of that hit
  * point; in f64 the reference's expression sees |c| ~ 1e-15 and its near root falls below t_min,
@@ -368,7 +417,8 @@ template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
 }
 
 /* ---------------------------------------------------------------- the world in Real */
-template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K, inv_radius; /* |center|^2 - r^2 and 1/r: throughput arithmetic only */ };
+template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K, inv_radius; /* |center|^2 - r^2 and 1/r: throughput arithmetic only */
+                                        vec3<float> center32; float Km; /* mixed mode's filter record */ };
 template <class Real> struct camera_t {
     vec3<Real> position, du, dv, top_left, dof_u, dof_v;
     Real dof_angle;
@@ -380,12 +430,21 @@ template <class Real> struct scene_t {
     std::vector<material_t<Real>> materials;
     camera_t<Real> cam;
     int64_t max_ray_bounces;
+    float filter_reach = 0.0f;  /* mixed mode: max |center| + |r| of the f32 records, rounded up */
+    bool filter_ok = true;      /* every sphere inside the range the filter's bound needs */
     scene_t(const rt_camera_render_data *c, const rt_sphere *s, int64_t ns, const rt_material *m, int64_t nm) {
         spheres.resize(ns);
-        for (int64_t i = 0; i < ns; ++i)
+        double reach = 0.0;
+        for (int64_t i = 0; i < ns; ++i) {
+            const float cx = static_cast<float>(s[i].center.x), cy = static_cast<float>(s[i].center.y), cz = static_cast<float>(s[i].center.z), rf = static_cast<float>(s[i].radius);
             spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index,
-                          sphere_constant(static_cast<float>(s[i].center.x), static_cast<float>(s[i].center.y), static_cast<float>(s[i].center.z), static_cast<float>(s[i].radius)),
-                          1.0f / static_cast<float>(s[i].radius)};
+                          sphere_constant(cx, cy, cz, rf), 1.0f / rf, {cx, cy, cz}, sphere_constant_lowered(cx, cy, cz, rf)};
+            const double far = std::sqrt(static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz) + std::fabs(static_cast<double>(rf));
+            reach = std::max(reach, far);
+            if (!(std::fabs(static_cast<double>(rf)) >= 1.0 / 1048576.0) || !(far <= 1048576.0)) filter_ok = false;
+        }
+        filter_reach = static_cast<float>(reach);
+        if (static_cast<double>(filter_reach) < reach) filter_reach = std::nextafterf(filter_reach, INFINITY);
         materials.resize(nm);
         for (int64_t i = 0; i < nm; ++i) materials[i] = {m[i].type, cvt<Real>(m[i].albedo), static_cast<Real>(m[i].param1)};
         cam = {cvt<Real>(c->position), cvt<Real>(c->pixel_delta_u), cvt<Real>(c->pixel_delta_v),
@@ -397,8 +456,9 @@ template <class Real> struct scene_t {
 
 /* one sample of one pixel: main.odin:518-575.  returns sample_color; adds executed
  * bounce-loop iterations to *segments. */
-template <class Real, bool FMA>
-inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t u, int64_t v, int64_t width, uint32_t sample, uint64_t *segments) {
+struct filter_counters { uint64_t kept = 0, wrongly_dropped = 0; };
+template <class Real, bool FMA, bool MIXED = false>
+inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t u, int64_t v, int64_t width, uint32_t sample, uint64_t *segments, filter_counters *fc = nullptr) {
     const camera_t<Real> &cam = sc.cam;
     const uint32_t pixel = static_cast<uint32_t>(u + v * width);
     draw_stream cg(keys, pixel, sample, 0);
@@ -429,6 +489,15 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             for (int64_t i = 0; i < n; ++i) {
                 if (i == start_sphere) continue;
                 Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                if (t < closest_t) { closest_t = t; hit_index = i; }
+            }
+        } else if constexpr (MIXED) {
+            const filter_ray f = make_filter_ray(ray, sc.filter_reach);
+            for (int64_t i = 0; i < n; ++i) {
+                const bool keep = !sc.filter_ok || mixed_filter(f, sc.spheres[i].center32, sc.spheres[i].Km);
+                Real t = ray_sphere_intersection<Real>(ray, sc.spheres[i].center, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                if (!keep) { if (t < closest_t) ++fc->wrongly_dropped; continue; } /* evaluated only to audit the filter */
+                ++fc->kept;
                 if (t < closest_t) { closest_t = t; hit_index = i; }
             }
         } else {
@@ -501,7 +570,7 @@ inline double q32_32_to_f64(uint64_t v) {
  *   order in which the GPU combines its per-chunk partial sums).
  * QACC = true (f32 throughput arithmetic): each f32 sample colour is converted to Q32.32 and
  *   summed exactly in u64; mean and square root are taken in f64. */
-template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
+template <class Real, bool FMA, bool QACC, bool MIXED = false> void render(const render_args &A) {
     scene_t<Real> sc(A.cam, A.spheres, A.n_spheres, A.materials, A.n_materials);
     const seed_keys keys = keys_from_seed(A.seed);
     const Real contribution = Real(1) / static_cast<Real>(A.sample_count); /* main.odin:512 */
@@ -509,9 +578,10 @@ template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
     const int64_t chunks = std::max<int64_t>(1, A.sample_chunks);
     const int64_t per = (A.sample_count + chunks - 1) / chunks;
     std::atomic<int64_t> next_row{A.region.min_y};
-    std::atomic<uint64_t> total_segments{0};
+    std::atomic<uint64_t> total_segments{0}, total_kept{0}, total_wrong{0};
     auto work = [&]() {
         uint64_t segments = 0;
+        filter_counters fc;
         for (;;) {
             int64_t v = next_row.fetch_add(1);
             if (v >= A.region.one_past_max_y) break;
@@ -536,7 +606,7 @@ template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
                     vec3<Real> part{0, 0, 0};
                     int64_t lo = c * per, hi = std::min(A.sample_count, (c + 1) * per);
                     for (int64_t s = lo; s < hi; ++s)
-                        part = part + trace_sample<Real, FMA>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments);
+                        part = part + trace_sample<Real, FMA, MIXED>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments, &fc);
                     pixel_color = (chunks == 1) ? part : pixel_color + part;
                 }
                 if (A.accum) { A.accum[index * 3 + 0] = pixel_color.x; A.accum[index * 3 + 1] = pixel_color.y; A.accum[index * 3 + 2] = pixel_color.z; }
@@ -551,6 +621,8 @@ template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
             }
         }
         total_segments += segments;
+        total_kept += fc.kept;
+        total_wrong += fc.wrongly_dropped;
     };
     int32_t nt = std::max(1, A.threads);
     if (nt == 1) work();
@@ -565,6 +637,7 @@ template <class Real, bool FMA, bool QACC> void render(const render_args &A) {
         A.stats[RT_STAT_SEGMENTS] = total_segments.load();
         A.stats[RT_STAT_SPHERE_TESTS] = total_segments.load() * static_cast<uint64_t>(A.n_spheres);
         A.stats[RT_STAT_SAMPLES] = npix * static_cast<uint64_t>(A.sample_count);
+        if (MIXED) { A.stats[5] = total_kept.load(); A.stats[6] = total_wrong.load(); } /* spheres the filter kept / dropped although hit */
     }
 }
 
@@ -595,8 +668,23 @@ int32_t oracle_render_region(int32_t precision, double *image, double *linear, d
     case RT_PRECISION_F64: render<double, false, false>(A); return 0;
     case RT_PRECISION_F32: render<float, true, true>(A); return 0;
     case RT_PRECISION_F32_LITERAL: render<float, false, false>(A); return 0;
+    case RT_PRECISION_MIXED: render<double, false, false, true>(A); return 0;
     default: return -1;
     }
+}
+
+/* The mixed mode's filter for one ray and one sphere, with its intermediate values:
+ * out = {lowered discriminant, lowered a*c, h, behind, in_range (0/1), kept (0/1)} */
+void oracle_mixed_filter(const double *o, const double *d, const double *c, double radius, double reach, double *out) {
+    ray_t<double> r{{o[0], o[1], o[2]}, {d[0], d[1], d[2]}};
+    const filter_ray f = make_filter_ray(r, static_cast<float>(reach));
+    const vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
+    const float Km = sphere_constant_lowered(cf.x, cf.y, cf.z, (float)radius);
+    const expanded_ray &e = f.e;
+    const float h = std::fmaf(cf.z, e.dz, std::fmaf(cf.y, e.dy, std::fmaf(cf.x, e.dx, -e.d_o)));
+    const float m = std::fmaf(Km, e.a, std::fmaf(cf.z, e.aoz, std::fmaf(cf.y, e.aoy, std::fmaf(cf.x, e.aox, e.aoo))));
+    out[0] = std::fmaf(h, h, -m); out[1] = m; out[2] = h; out[3] = f.behind; out[4] = f.in_range ? 1.0 : 0.0;
+    out[5] = mixed_filter(f, cf, Km) ? 1.0 : 0.0;
 }
 
 /* ray_sphere_intersection with explicit inputs (o, d, c are 3 doubles each) */

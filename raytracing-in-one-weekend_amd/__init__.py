@@ -26,7 +26,7 @@ RT_ERR_DEVICE = -3
 RT_ERR_UNSUPPORTED = -4
 RT_ERR_BUFFER_TOO_SMALL = -5
 LAMBERTIAN, METALLIC, DIELECTRIC = 0, 1, 2
-PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL = 0, 1, 2
+PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL, PRECISION_MIXED = 0, 1, 2, 3
 FETCH_AUTO, FETCH_SCALAR, FETCH_LDS, FETCH_BVH, FETCH_BVH_GLOBAL = 0, 1, 2, 3, 4
 RNG_STOCHASTIC, RNG_DETERMINISTIC = 0, 1
 STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES, STAT_WAVE_ITERATIONS, STAT_BVH_NODES, STAT_BVH_TESTS = 0, 1, 2, 3, 4, 5, 6

@@ -39,10 +39,12 @@ int32_t fail(int32_t code, const char *fmt, ...) {
     } while (0)
 
 // One lock per device ordinal: the one-shot entry points may be called from several host
-// threads (the reference calls render_region from pool threads, main.odin:609).
+// threads (the reference calls render_region from pool threads, main.odin:609).  Ordinals are
+// validated against MAX_DEVICES before any table indexed by them is touched.
+constexpr int MAX_DEVICES = 64;
 std::mutex &device_mutex(int device) {
-    static std::mutex m[64];
-    return m[(device >= 0 && device < 64) ? device : 0];
+    static std::mutex m[MAX_DEVICES];
+    return m[device];
 }
 
 uint32_t mix32(uint32_t x) {
@@ -56,7 +58,7 @@ void seed_keys(uint64_t seed, uint32_t &k0, uint32_t &k1) {
     k1 = mix32(static_cast<uint32_t>(seed >> 32) ^ k0 ^ 0x85ebca6bu);
 }
 
-bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL; }
+bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL || p == RT_PRECISION_MIXED; }
 size_t accum_size(int32_t precision) { return rtk::accum_element_size(precision); }
 
 struct DeviceGuard {
@@ -77,13 +79,29 @@ struct DeviceGuard {
 
 } // namespace
 
+// What one rt_render_accumulate call owns while it is in flight: a work-queue head and the two
+// events that time it.  A world holds a small ring of them, so calls on different streams do not
+// share a queue head.
+struct CallSlot {
+    uint32_t *queue = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool used = false;
+};
+constexpr int CALL_SLOTS = 8;
+
 struct rt_world_s {
     int device = 0;
     int32_t n_spheres = 0, n_padded = 0, n_materials = 0;
     int resident_blocks = 2048;                 // workgroups the device can hold at once
-    uint32_t *queue = nullptr;                  // head of the work queue of the throughput kernel
+    uint32_t *queue_ring = nullptr;             // CALL_SLOTS work-queue heads, 64 bytes apart
+    CallSlot slots[CALL_SLOTS];
+    uint64_t n_calls = 0;
+    int last_slot = -1;
     void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
     void *rec32k = nullptr;                     // {cx, cy, cz, |c|^2 - r*r}: the throughput kernel's records
+    void *rec32m = nullptr;                     // the same pairs with K lowered by the mixed mode's filter margin
+    float filter_reach = 0.0f;                  // max |c| + |r| over the spheres, rounded up
+    bool filter_ok = true;                      // every sphere inside the range the filter's error bound needs
     void *rad32 = nullptr, *rad64 = nullptr;
     void *rad32inv = nullptr;                   // 1/radius in f32, the throughput kernel's hit normal is (p - c) * (1/r)
     int32_t *sphere_material = nullptr;
@@ -96,10 +114,14 @@ struct rt_world_s {
     int32_t bvh_n_nodes = 0;
     bool bvh_built = false;
     rtk::BvhHost bvh_host;                      // grid and big-sphere list (node and sphere vectors are released after upload)
-    void *slabs = nullptr;                      // partial sums of sample chunks 1..
+    // Scratch the kernels of a call write and read: partial sums of sample chunks 1.. (literal modes)
+    // or the staged sample colours (mixed mode).  One buffer per world: a call that uses it on
+    // another stream than the previous such call first waits (on the device) for that call's end.
+    void *slabs = nullptr;
     size_t slab_bytes = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    bool timed = false;
+    hipEvent_t slabs_done = nullptr;
+    hipStream_t slabs_stream = nullptr;
+    bool slabs_busy = false;
     std::mutex mu;
 };
 
@@ -222,11 +244,13 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     // record has r*r = -inf, which makes its discriminant -inf (or NaN): never a candidate
     const size_t ns_pad = (ns + rtk::SCAN_STEP - 1) / rtk::SCAN_STEP * rtk::SCAN_STEP;
     const size_t ns_alloc = ns_pad + rtk::GROUP;
-    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32k(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
+    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32k(4 * ns_alloc, 0.0f), rec32m(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
     // throughput records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
     auto pair_slot = [](size_t i, int component) { return 8 * (i / 2) + 2 * component + (i % 2); };
-    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32k[pair_slot(i, 3)] = 3.402823466e+38f; }
+    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32k[pair_slot(i, 3)] = 3.402823466e+38f; rec32m[pair_slot(i, 3)] = 3.402823466e+38f; }
+    double reach = 0.0;
+    bool filter_ok = true;
     std::vector<int32_t> smat(ns), mtype(nm);
     for (size_t i = 0; i < ns; ++i) {
         const rt_sphere &s = spheres[i];
@@ -235,8 +259,21 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         rec32[4 * i + 2] = static_cast<float>(s.center.z); rec32[4 * i + 3] = r * r; // sphere_radius*sphere_radius, main.odin:248
         for (int k = 0; k < 3; ++k) rec32k[pair_slot(i, k)] = rec32[4 * i + k];
         // K = |centre|^2 - r^2 of the f32 centre and radius, formed in f64 and rounded once
-        rec32k[pair_slot(i, 3)] = static_cast<float>(static_cast<double>(rec32[4 * i]) * rec32[4 * i] + static_cast<double>(rec32[4 * i + 1]) * rec32[4 * i + 1] +
-                                               static_cast<double>(rec32[4 * i + 2]) * rec32[4 * i + 2] - static_cast<double>(r) * r);
+        const double c2 = static_cast<double>(rec32[4 * i]) * rec32[4 * i] + static_cast<double>(rec32[4 * i + 1]) * rec32[4 * i + 1] + static_cast<double>(rec32[4 * i + 2]) * rec32[4 * i + 2];
+        const double r2 = static_cast<double>(r) * r;
+        rec32k[pair_slot(i, 3)] = static_cast<float>(c2 - r2);
+        // mixed mode: K lowered by the sphere's share of the filter margin, 2^-17 (|c|^2 + r^2), and rounded down
+        {
+            const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 131072.0);
+            float km = static_cast<float>(lowered);
+            if (static_cast<double>(km) > lowered) km = std::nextafterf(km, -INFINITY);
+            for (int k = 0; k < 3; ++k) rec32m[pair_slot(i, k)] = rec32[4 * i + k];
+            rec32m[pair_slot(i, 3)] = km;
+            const double far = std::sqrt(c2) + std::fabs(static_cast<double>(r));
+            reach = std::max(reach, far);
+            // the filter's error bound holds while every product stays a normal f32 number
+            if (!(std::fabs(static_cast<double>(r)) >= 1.0 / 1048576.0) || !(far <= 1048576.0)) filter_ok = false;
+        }
         rec64[4 * i + 0] = s.center.x; rec64[4 * i + 1] = s.center.y; rec64[4 * i + 2] = s.center.z; rec64[4 * i + 3] = s.radius * s.radius;
         rad32[i] = r; rad64[i] = s.radius; rad32inv[i] = 1.0f / r;
         smat[i] = static_cast<int32_t>(s.material_index);
@@ -252,6 +289,9 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     w->h_k.resize(ns);
     for (size_t i = 0; i < ns; ++i) w->h_k[i] = rec32k[pair_slot(i, 3)];
     w->h_rad32 = rad32; w->h_rad32inv = rad32inv; w->h_material = smat;
+    w->filter_ok = filter_ok;
+    w->filter_reach = static_cast<float>(reach);
+    if (static_cast<double>(w->filter_reach) < reach) w->filter_reach = std::nextafterf(w->filter_reach, INFINITY);
     w->device = current;
     w->n_spheres = static_cast<int32_t>(n_spheres);
     w->n_padded = static_cast<int32_t>(ns_pad);
@@ -265,6 +305,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload(&w->rec32, rec32.data(), rec32.size() * 4);
     if (e == hipSuccess) e = upload(&w->rec32k, rec32k.data(), rec32k.size() * 4);
+    if (e == hipSuccess) e = upload(&w->rec32m, rec32m.data(), rec32m.size() * 4);
     if (e == hipSuccess) e = upload(&w->rec64, rec64.data(), rec64.size() * 8);
     if (e == hipSuccess) e = upload(&w->rad32, rad32.data(), rad32.size() * 4);
     if (e == hipSuccess) e = upload(&w->rad64, rad64.data(), rad64.size() * 8);
@@ -273,7 +314,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     if (e == hipSuccess) e = upload(&w->mat32, mat32.data(), mat32.size() * 4);
     if (e == hipSuccess) e = upload(&w->mat64, mat64.data(), mat64.size() * 8);
     if (e == hipSuccess) e = upload(reinterpret_cast<void **>(&w->material_type), mtype.data(), mtype.size() * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w->queue), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w->queue_ring), 64 * CALL_SLOTS);
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, current);
@@ -281,8 +322,12 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         // (late workgroups find the queue empty), a smaller one would leave CUs idle
         if (e == hipSuccess) w->resident_blocks = std::max(1, prop.multiProcessorCount) * (2048 / rtk::BLOCK_THREADS);
     }
-    if (e == hipSuccess) e = hipEventCreate(&w->ev_begin);
-    if (e == hipSuccess) e = hipEventCreate(&w->ev_end);
+    for (int k = 0; k < CALL_SLOTS && e == hipSuccess; ++k) {
+        w->slots[k].queue = w->queue_ring + 16 * k;
+        e = hipEventCreate(&w->slots[k].ev_begin);
+        if (e == hipSuccess) e = hipEventCreate(&w->slots[k].ev_end);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w->slabs_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         rt_world_destroy(w);
         return fail(RT_ERR_DEVICE, "uploading the world failed: %s", hipGetErrorString(e));
@@ -295,18 +340,48 @@ int32_t rt_world_destroy(rt_world *w) {
     if (w == nullptr) return RT_OK;
     DeviceGuard guard;
     (void)guard.enter(w->device);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue, w->bvh_nodes, w->bvh_spheres, w->bvh_lds_boxes, w->bvh_lds_links};
+    // calls still in flight read the buffers freed below
+    for (CallSlot &c : w->slots) if (c.used && c.ev_end) (void)hipEventSynchronize(c.ev_end);
+    void *bufs[] = {w->rec32, w->rec32k, w->rec32m, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue_ring, w->bvh_nodes, w->bvh_spheres, w->bvh_lds_boxes, w->bvh_lds_links};
     for (void *b : bufs) if (b) (void)hipFree(b);
-    if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
-    if (w->ev_end) (void)hipEventDestroy(w->ev_end);
+    for (CallSlot &c : w->slots) {
+        if (c.ev_begin) (void)hipEventDestroy(c.ev_begin);
+        if (c.ev_end) (void)hipEventDestroy(c.ev_end);
+    }
+    if (w->slabs_done) (void)hipEventDestroy(w->slabs_done);
     delete w;
     return RT_OK;
 }
 
-int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
-                             int64_t strip_rows, int32_t strip_index, int32_t strip_count,
-                             int64_t sample_begin, int64_t sample_count, uint64_t seed, int32_t precision, int32_t sphere_fetch,
-                             int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
+} // extern "C"
+
+namespace {
+
+// Where a call's device scratch comes from.  The regular entry point takes the queue head from the
+// world's ring and lets the world's scratch buffer grow (hipMalloc); the entry point that allocates
+// nothing brings one fixed region per device and fails when the call does not fit.
+struct ScratchSource {
+    uint32_t *queue = nullptr;   // NULL: use the call slot's
+    void *work = nullptr;        // NULL: the world's buffer, grown on demand
+    size_t work_bytes = 0;
+    bool fixed = false;
+};
+
+// default upper bound of the mixed mode's staging buffer (it holds 24 bytes per pixel and staged sample;
+// a call whose samples do not fit is run as several launches); RT_MI355X_STAGING_MIB overrides it
+size_t staging_budget() {
+    const char *env = std::getenv("RT_MI355X_STAGING_MIB");
+    if (env != nullptr && env[0] != '\0') {
+        const long long mib = std::atoll(env);
+        if (mib > 0) return static_cast<size_t>(mib) << 20;
+    }
+    return static_cast<size_t>(12) << 30;
+}
+
+int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
+                        int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                        int64_t sample_begin, int64_t sample_count, uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                        int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream, ScratchSource src) {
     if (world == nullptr || cam == nullptr || d_accum == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world, cam or d_accum is NULL");
     if (!precision_ok(precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
     if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH_GLOBAL) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
@@ -321,16 +396,22 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     if (rc != RT_OK) return rc;
     if (wk.map.n_tiles == 0) return RT_OK;
 
-    const bool f64 = precision == RT_PRECISION_F64;
+    // The mixed mode's filter needs a world inside its range; any other world is traced by the f64
+    // kernel with one sample chunk, which is the same arithmetic and the same summation order.
+    bool mixed = precision == RT_PRECISION_MIXED;
+    if (mixed && !world->filter_ok) { mixed = false; precision = RT_PRECISION_F64; sample_chunks = 1; }
+    if (mixed && sphere_fetch == RT_FETCH_LDS) return fail(RT_ERR_UNSUPPORTED, "RT_PRECISION_MIXED reads its filter records through the scalar cache only");
+
+    const bool f64 = precision == RT_PRECISION_F64 || mixed;
     int fetch = sphere_fetch == RT_FETCH_AUTO ? RT_FETCH_SCALAR : sphere_fetch;
     if (fetch == RT_FETCH_LDS && world->n_spheres > (f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32))
         return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_LDS holds at most %d spheres at this precision, the world has %d",
                     f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32, world->n_spheres);
 
-    const bool queue_mode = precision == RT_PRECISION_F32;
-    int chunks = sample_chunks > 0 ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count) : auto_chunks(wk.map.n_tiles, sample_count));
+    const bool queue_mode = precision == RT_PRECISION_F32 || mixed;
+    int chunks = sample_chunks > 0 && !mixed ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count) : auto_chunks(wk.map.n_tiles, sample_count));
     chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, sample_count))));
-    const int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
+    int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
     chunks = sample_count == 0 ? 1 : static_cast<int>((sample_count + chunk_samples - 1) / chunk_samples);
     if (static_cast<int64_t>(wk.map.n_tiles) * chunks > (int64_t(1) << 31) - 1) return fail(RT_ERR_UNSUPPORTED, "%d tiles x %d sample chunks exceed 2^31 work items", wk.map.n_tiles, chunks);
 
@@ -338,17 +419,41 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     DeviceGuard guard;
     HIP_TRY(guard.enter(world->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t slab_stride = width * height * 3;
-    if (chunks > 1 && !queue_mode) {
-        const size_t need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * accum_size(precision);
-        if (need > world->slab_bytes) {
-            if (world->slabs) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(world->slabs)); world->slabs = nullptr; world->slab_bytes = 0; }
-            HIP_TRY(hipMalloc(&world->slabs, need));
-            world->slab_bytes = need;
+    const int64_t slab_stride = mixed ? static_cast<int64_t>(wk.map.n_tiles) * 64 * 3 : width * height * 3;
+
+    // scratch beyond the queue head: chunk slabs (literal modes) or staged sample colours (mixed mode)
+    size_t work_need = 0;
+    int64_t window = sample_count; // mixed mode: samples staged per launch
+    if (mixed) {
+        const size_t per_sample = static_cast<size_t>(slab_stride) * sizeof(double);
+        const size_t all = per_sample * static_cast<size_t>(std::max<int64_t>(sample_count, 1));
+        const size_t cap = src.fixed ? src.work_bytes : std::max(per_sample, std::min(all, staging_budget()));
+        if (cap < per_sample) return fail(RT_ERR_UNSUPPORTED, "one staged sample of this call needs %zu bytes of scratch, %zu are available", per_sample, cap);
+        window = std::max<int64_t>(1, std::min<int64_t>(sample_count, static_cast<int64_t>(cap / per_sample)));
+        if (window < sample_count && window >= 4) window = window / 4 * 4; // whole work items
+        work_need = per_sample * static_cast<size_t>(window);
+    } else if (chunks > 1 && !queue_mode) {
+        work_need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * accum_size(precision);
+    }
+    void *work = nullptr;
+    if (work_need > 0) {
+        if (src.fixed) {
+            if (work_need > src.work_bytes) return fail(RT_ERR_UNSUPPORTED, "the call needs %zu bytes of scratch for its %d sample chunks, the fixed region holds %zu", work_need, chunks, src.work_bytes);
+            work = src.work;
+        } else {
+            if (work_need > world->slab_bytes) {
+                if (world->slabs) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(world->slabs)); world->slabs = nullptr; world->slab_bytes = 0; world->slabs_busy = false; }
+                HIP_TRY(hipMalloc(&world->slabs, work_need));
+                world->slab_bytes = work_need;
+            }
+            work = world->slabs;
+            // the previous user of the buffer may still be running on another stream
+            if (world->slabs_busy && world->slabs_stream != st) HIP_TRY(hipStreamWaitEvent(st, world->slabs_done, 0));
         }
     }
 
     if (fetch == RT_FETCH_BVH && !world->bvh_built) {
+        if (src.fixed) return fail(RT_ERR_UNSUPPORTED, "the hierarchy of RT_FETCH_BVH is built and uploaded by the first rt_render_accumulate that asks for it");
         rtk::BvhHost &bvh = world->bvh_host;
         rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
         // a previous attempt may have failed half way: start from nothing
@@ -372,6 +477,13 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         world->bvh_built = true;
     }
 
+    // this call's slot: its own queue head and events; a slot is reused only after its last call has ended
+    const int slot_index = static_cast<int>(world->n_calls % CALL_SLOTS);
+    CallSlot &slot = world->slots[slot_index];
+    if (slot.used) HIP_TRY(hipEventSynchronize(slot.ev_end));
+    ++world->n_calls;
+    uint32_t *queue = src.queue != nullptr ? src.queue : slot.queue;
+
     rtk::RenderParams p{};
     p.bvh_nodes = world->bvh_nodes; p.bvh_spheres = world->bvh_spheres; p.bvh_n_nodes = world->bvh_n_nodes;
     if (!bvh_global_only) { p.bvh_lds_boxes = world->bvh_lds_boxes; p.bvh_lds_links = world->bvh_lds_links; }
@@ -382,7 +494,8 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
         static_assert(sizeof(rtk::BvhSphere) == sizeof(p.bvh_big[0]), "big-sphere records are copied bytewise");
         std::memcpy(p.bvh_big, bvh.big, sizeof(rtk::BvhSphere) * static_cast<size_t>(bvh.n_big));
     }
-    p.sphere_rec = f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32);
+    p.sphere_rec = mixed ? world->rec32m : (f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32));
+    p.filter_reach = world->filter_reach;
     p.sphere_center = f64 ? world->rec64 : world->rec32;
     p.sphere_radius = f64 ? world->rad64 : (precision == RT_PRECISION_F32 ? world->rad32inv : world->rad32);
     p.sphere_material = world->sphere_material;
@@ -396,37 +509,73 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     p.sample_count = static_cast<uint32_t>(sample_count);
     p.chunk_samples = static_cast<uint32_t>(chunk_samples);
     p.n_items = static_cast<uint32_t>(static_cast<int64_t>(wk.map.n_tiles) * chunks);
-    p.queue = world->queue;
+    p.queue = queue;
     p.max_bounces = static_cast<int32_t>(cam->max_ray_bounces);
     seed_keys(seed, p.k0, p.k1);
     p.accum = d_accum;
-    p.slabs = world->slabs;
+    p.slabs = work;
     p.slab_stride = slab_stride;
     p.stats = reinterpret_cast<unsigned long long *>(d_stats);
     pack_camera(cam, p.cam32, p.cam64);
 
     rtk::ReduceParams r{};
-    r.accum = d_accum; r.slabs = world->slabs; r.slab_stride = slab_stride; r.chunks = chunks;
+    r.accum = d_accum; r.slabs = work; r.slab_stride = slab_stride; r.chunks = chunks;
     r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
-    HIP_TRY(hipEventRecord(world->ev_begin, st));
-    if (queue_mode) HIP_TRY(rtk::launch_clear(r, world->queue, st));
-    HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, world->resident_blocks, st));
-    if (chunks > 1 && !queue_mode) HIP_TRY(rtk::launch_reduce(r, precision, st));
-    HIP_TRY(hipEventRecord(world->ev_end, st));
-    world->timed = true;
+    HIP_TRY(hipEventRecord(slot.ev_begin, st));
+    slot.used = true; // from here on something of this call may be in flight
+    world->last_slot = slot_index;
+    if (mixed) {
+        // samples in windows of what the staging buffer holds: trace a window (any order), then add its
+        // colours to the accumulators in sample order
+        for (int64_t w0 = 0; w0 < std::max<int64_t>(sample_count, 1); w0 += window) {
+            const int64_t wc = std::min<int64_t>(window, sample_count - w0);
+            const int wchunks = static_cast<int>(std::max<int64_t>(1, (wc + 3) / 4));
+            p.sample_begin = static_cast<uint32_t>(sample_begin + w0);
+            p.sample_count = static_cast<uint32_t>(wc);
+            p.chunk_samples = 4u;
+            p.n_items = static_cast<uint32_t>(static_cast<int64_t>(wk.map.n_tiles) * wchunks);
+            r.chunks = static_cast<int32_t>(wc);
+            HIP_TRY(rtk::launch_clear_queue(queue, st));
+            if (wc > 0) HIP_TRY(rtk::launch_render(p, rtk::ARITH_MIXED, fetch, wchunks, world->resident_blocks, st));
+            HIP_TRY(rtk::launch_order_sum(r, w0 == 0, st));
+        }
+    } else {
+        if (queue_mode) HIP_TRY(rtk::launch_clear(r, queue, st));
+        HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, world->resident_blocks, st));
+        if (chunks > 1 && !queue_mode) HIP_TRY(rtk::launch_reduce(r, precision, st));
+    }
+    HIP_TRY(hipEventRecord(slot.ev_end, st));
+    if (work != nullptr && !src.fixed) {
+        HIP_TRY(hipEventRecord(world->slabs_done, st));
+        world->slabs_busy = true;
+        world->slabs_stream = st;
+    }
     return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
+                             int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                             int64_t sample_begin, int64_t sample_count, uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                             int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
+    return accumulate_impl(world, cam, width, height, region, strip_rows, strip_index, strip_count, sample_begin, sample_count, seed, precision,
+                           sphere_fetch, sample_chunks, d_accum, d_stats, stream, ScratchSource{});
 }
 
 int64_t rt_world_last_kernel_ns(rt_world *world) {
     if (world == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world is NULL");
     std::lock_guard<std::mutex> lock(world->mu);
-    if (!world->timed) return fail(RT_ERR_INVALID_ARGUMENT, "no render has been launched on this world");
+    if (world->last_slot < 0) return fail(RT_ERR_INVALID_ARGUMENT, "no render has been launched on this world");
     DeviceGuard guard;
     if (guard.enter(world->device) != hipSuccess) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
-    hipError_t e = hipEventSynchronize(world->ev_end);
+    const CallSlot &slot = world->slots[world->last_slot];
+    hipError_t e = hipEventSynchronize(slot.ev_end);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventSynchronize failed: %s", hipGetErrorString(e));
     float ms = 0.f;
-    e = hipEventElapsedTime(&ms, world->ev_begin, world->ev_end);
+    e = hipEventElapsedTime(&ms, slot.ev_begin, slot.ev_end);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventElapsedTime failed: %s", hipGetErrorString(e));
     return static_cast<int64_t>(static_cast<double>(ms) * 1e6);
 }

@@ -18,7 +18,9 @@ constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 record
 // ARITH_F32_FMA    : f32, fused scan, work queue, accumulators are Q32.32 in uint64 (atomic adds)
 // ARITH_F64        : f64, reference operation order, accumulators are double
 // ARITH_F32_LITERAL: f32, reference operation order, accumulators are float
-enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2 };
+// ARITH_MIXED      : f64, reference operation order, behind the packed-f32 scan used as a conservative
+//                    filter; work queue; every sample colour is staged and summed in sample order
+enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2, ARITH_MIXED = 3 };
 inline size_t accum_element_size(int arith) { return arith == ARITH_F32_LITERAL ? 4 : 8; }
 enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2, FETCH_BVH = 3 };
 
@@ -41,7 +43,9 @@ struct TileMap {
 struct RenderParams {
     // world, structure of arrays (device pointers)
     const void *sphere_rec;     // scan records: float4 / double4 {cx, cy, cz, r*r}; throughput mode: per PAIR of spheres
-                                // {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} with K = |c|^2 - r*r
+                                // {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} with K = |c|^2 - r*r; mixed mode: the same
+                                // pairs with K lowered by the filter's margin 2^-17 (|c|^2 + r*r)
+    float filter_reach;         // mixed mode: max over spheres of |c| + |r|, rounded up
     const void *sphere_center;  // float4 / double4 {cx, cy, cz, r*r}: the centre is read from here on a hit
     const void *sphere_radius;  // per sphere radius, float / double (throughput mode: 1/radius)
     const int32_t *sphere_material;
@@ -70,8 +74,9 @@ struct RenderParams {
     int32_t max_bounces;
     uint32_t k0, k1;         // RNG seed keys
     void *accum;             // width*height*3 sums (element type: see Arith); literal modes: chunk 0 writes here
-    void *slabs;             // chunk c >= 1 writes to slabs + (c-1)*slab_stride (same layout)
-    int64_t slab_stride;     // elements per slab
+    void *slabs;             // chunk c >= 1 writes to slabs + (c-1)*slab_stride (same layout); mixed mode: the
+                             // staged sample colours, sample s of the launch at slabs + s*slab_stride
+    int64_t slab_stride;     // elements per slab (mixed mode: owned tiles * 64 * 3)
     unsigned long long *stats; // optional device counters
     CameraF32 cam32;
     CameraF64 cam64;
@@ -88,6 +93,10 @@ struct ReduceParams {
 hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream);
 // queue mode: zero the owned pixels' accumulators and the queue head
 hipError_t launch_clear(const ReduceParams &p, uint32_t *queue, hipStream_t stream);
+// mixed mode: zero the queue head only
+hipError_t launch_clear_queue(uint32_t *queue, hipStream_t stream);
+// mixed mode: accum[p] = (first ? 0 : accum[p]) + staged_0[p] + staged_1[p] + ... for p.chunks staged samples, in order
+hipError_t launch_order_sum(const ReduceParams &p, bool first, hipStream_t stream);
 
 struct FinalizeParams {
     const void *accum; double *image; double *linear; // image/linear: 3 doubles per pixel

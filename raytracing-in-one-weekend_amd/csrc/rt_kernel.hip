@@ -172,9 +172,17 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 
 // BVH: 0 = list scan; 1 = hierarchy in global memory (16-byte nodes, one order per direction octant);
 //      2 = hierarchy in LDS (boxes once, 16-bit links per octant), for hierarchies small enough
-template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0>
+// MIXED: f64 paths in the reference's literal operation order (Real = double, FMA = false) whose
+//        closest-hit scan is preceded by the packed-f32 filter of the throughput mode, made
+//        conservative: a sphere is dropped only when its discriminant is negative by more than every
+//        rounding error the f32 evaluation can have made.  Samples are dealt to free lanes (QUEUE)
+//        and every finished sample colour is stored, so that a second kernel can add them in
+//        sample order (main.odin:575).
+template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0, bool MIXED = false>
 __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
     static_assert(BVH == 0 || (FMA && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in the throughput arithmetic only");
+    static_assert(!MIXED || (std::is_same<Real, double>::value && !FMA && QUEUE && FETCH == FETCH_SCALAR && BVH == 0), "the mixed mode is f64 literal arithmetic behind the scalar-fetch f32 filter");
+    constexpr bool FILTER = FMA || MIXED; // the scan is the packed-f32 candidate filter
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of SCAN_STEP
@@ -230,8 +238,10 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     bool inside = false;
     // queue mode, all wave-uniform: the current item and its (pixel, sample) pairs
     uint32_t pair_next = 0, pair_total = 0, npx = 0, item_s_begin = 0;
-    int x0 = 0, y0 = 0, tw = TILE;
+    int x0 = 0, y0 = 0, tw = TILE, item_tile = 0;
     bool queue_open = true;
+    // mixed mode: where this lane's sample colour is stored, ((sample of the launch) * owned pixels + tile * 64 + pixel of the tile) * 3
+    int64_t stage_at = 0;
 
     if constexpr (!QUEUE) {
         const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     if (item >= P.n_items) { queue_open = false; break; }
                     const uint32_t chunk = item / static_cast<uint32_t>(P.map.n_tiles);
                     const int tile = static_cast<int>(item % static_cast<uint32_t>(P.map.n_tiles));
+                    item_tile = tile;
                     x0 = P.min_x + (tile % P.map.tiles_x) * TILE;
                     y0 = P.min_y + tile_row_of(P.map, tile / P.map.tiles_x) * TILE;
                     tw = min(TILE, P.max_x - x0);
@@ -304,6 +315,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
                     kp = mix32(P.k0 ^ pixel);
                     wp = mix32(P.k1 + pixel);
+                    if constexpr (MIXED)
+                        stage_at = static_cast<int64_t>(s) * P.slab_stride + (static_cast<int64_t>(item_tile) * 64 + (v - y0) * TILE + (u - x0)) * 3;
                     got = true;
                 }
                 const unsigned long long taken = __builtin_amdgcn_ballot_w64(take);
@@ -377,6 +390,25 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     }
                     if (!rejected && root < closest) { closest = root; hit = pend; }
                 }
+            } else if constexpr (MIXED) {
+                // ray_sphere_intersection as written (main.odin:245-261) in f64 for the parked
+                // candidate, then the caller's `t < closest_t` (:542-545).  The filter only decided
+                // that this sphere has to be looked at; nothing it computed is used here.
+                const R4 sp = static_cast<const R4 *>(P.sphere_center)[pend]; // {centre, r*r}
+                const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
+                const Real h = rd.x * ocx + rd.y * ocy + rd.z * ocz;
+                const Real cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                const Real disc = h * h - a * cc;
+                if (!(disc < Real(0))) {
+                    const Real sq = sqrt_rn(disc);
+                    Real root = (h - sq) / a;
+                    bool rejected = (root < t_min) || (closest <= root);
+                    if (rejected) {
+                        root = (h + sq) / a;
+                        rejected = (root < t_min) || (closest <= root);
+                    }
+                    if (!rejected && root < closest) { closest = root; hit = pend; }
+                }
             } else {
                 // main.odin:252-261 for the parked candidate, then :542-545
                 Real sq = sqrt_rn(pend_disc);
@@ -391,17 +423,23 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             pend = -1;
         };
         // the uncommon continuation for one sphere: some lane's line meets it
-        auto park = [&](const Real h, const Real cc, const Real disc, const int i) {
-            if (__builtin_amdgcn_ballot_w64(disc >= Real(0)) != 0ull) {
+        float behind = 0.0f; // mixed mode: h below -behind is certainly negative (set with the filter's per-ray values)
+        auto park = [&](const auto h, const auto cc, const auto disc, const int i) {
+            using T = decltype(disc);
+            // mixed mode: the filter's discriminant carries its error margin (see below), and a NaN keeps the sphere
+            const bool meets = MIXED ? !(disc < T(0)) : (disc >= T(0));
+            if (__builtin_amdgcn_ballot_w64(meets) != 0ull) {
                 // A line that meets the sphere only behind the origin (h <= 0) while the origin
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
                 // (the sphere the segment starts on was tested before the scan)
-                const bool cand = (disc >= Real(0)) && ((h > Real(0)) || (cc < Real(0))) && (!FMA || i != start_sphere);
+                // Mixed mode: only when both signs are certain despite the f32 rounding.
+                const bool ahead = MIXED ? !((h < T(-behind)) && (cc > T(0))) : ((h > T(0)) || (cc < T(0)));
+                const bool cand = meets && ahead && (!FMA || i != start_sphere);
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
                 }
                 if (cand) {
-                    if constexpr (!FMA) { pend_h = h; pend_disc = disc; }
+                    if constexpr (!FILTER) { pend_h = h; pend_disc = disc; }
                     pend = i;
                     RT_DIAG_COUNT(diag_parked);
                 }
@@ -411,7 +449,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         // hit, plus one more group, so the next group is always loadable while the current one
         // is tested.  One compare covers a group of four spheres: the largest of the four
         // discriminants (NaNs ignored) is negative in every lane for most groups.
-        if constexpr (FMA) {
+        if constexpr (FILTER) {
             // Throughput arithmetic.  The squares of main.odin:245-249 are expanded so that h and
             // a*c are dot products of a per-sphere record {centre, K = |centre|^2 - r^2} with
             // per-ray vectors:   h = d.centre - d.o      a*c = a*K - 2a centre.o + a|o|^2,
@@ -423,7 +461,30 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             // SGPR-pair source at full rate.  Pad records have K = FLT_MAX: a*c overflows and the
             // discriminant is -inf.  `park` receives a*c where the literal modes pass c: only its
             // sign is used there, and a > 0.
-            const float d_o = dot(rd, ro), o_o = dot(ro, ro);
+            //
+            // Mixed mode runs the same instructions on the f64 ray rounded to f32, as a filter that must
+            // never drop a sphere the f64 test of main.odin:245-261 would report as hit.  With
+            // u = 2^-24, S = |centre| + |o| + r and everything exact but the f32 roundings, the
+            // computed discriminant differs from the f64 one by at most 34 u a S^2: 8 from rounding
+            // d, o, centre and r to f32 (gradient of h^2 - a*c times the input errors), 12 from h
+            // (three fused roundings and the plain dot product d.o, doubled by squaring), 12 from
+            // a*c (K, the roundings of a, a*(-2o), a*|o|^2 and of the four fused operations), 2 from
+            // the last fused operation.  S^2 <= 3(|centre|^2 + r^2 + |o|^2), so lowering a*c by
+            // 2^-17 a (|centre|^2 + r^2 + |o|^2) = 42.7 u a S^2 covers it; that margin costs no
+            // instruction: the per-sphere part is folded into the record's K on the host, the
+            // per-ray part into a*|o|^2 here.  A sphere is kept when the lowered discriminant is not
+            // negative.  The bound needs every product to stay a normal f32 number: the world is
+            // checked for that on the host (2^-20 <= r, |centre| + r <= 2^20) and a ray outside
+            // 2^-40 <= a <= 2^40, |o|^2 <= 2^40 (or not a number) keeps every sphere.
+            float d_o, o_o, fa;
+            V3<float> fd, fo;
+            if constexpr (FMA) { fd = rd; fo = ro; fa = a; }
+            else {
+                fd = {static_cast<float>(rd.x), static_cast<float>(rd.y), static_cast<float>(rd.z)};
+                fo = {static_cast<float>(ro.x), static_cast<float>(ro.y), static_cast<float>(ro.z)};
+                fa = dot(fd, fd);
+            }
+            d_o = dot(fd, fo); o_o = dot(fo, fo);
             // The sphere this segment starts on: its origin is the previous hit point, so c is zero
             // up to the rounding of that point.  The reference's f64 arithmetic sees |c| ~ 1e-15
             // and its near root falls below t_min; in f32 the rounding of c is large enough to give
@@ -431,13 +492,27 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             // sphere: the roots of main.odin:249-258 become 0 and 2h/a, and only the second can be
             // a hit, for h > 0 (a segment through the inside).  It is tested first and left out
             // of the scan.
+            if constexpr (FMA) {
             if (start_sphere >= 0) {
                 const float ocx = start_center.x - ro.x, ocy = start_center.y - ro.y, ocz = start_center.z - ro.z;
                 const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a; // (d.oc)/a as in `resolve`
                 const float root = q + q;
                 if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
-            const float aox = a * (-2.0f * ro.x), aoy = a * (-2.0f * ro.y), aoz = a * (-2.0f * ro.z), aoo = a * o_o;
+            }
+            float aox = fa * (-2.0f * fo.x), aoy = fa * (-2.0f * fo.y), aoz = fa * (-2.0f * fo.z), aoo = fa * o_o;
+            if constexpr (MIXED) {
+                aoo = aoo * (1.0f - 7.62939453125e-06f); // the ray's share of the margin: 2^-17 a |o|^2
+                // h < -behind is certainly negative: h is off by at most 8 u |d| S, and S <= reach + |o|
+                behind = 9.5367431640625e-07f * sqrt_rn(fa) * (P.filter_reach + sqrt_rn(o_o)); // 2^-20 = 16 u
+                const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f); // 2^-40, 2^40
+                if (!in_range) {
+                    // every sphere is a candidate of this ray: h = 0, a*c = -1, discriminant 1
+                    fd = {0.0f, 0.0f, 0.0f}; d_o = 0.0f; fa = 0.0f;
+                    aox = 0.0f; aoy = 0.0f; aoz = 0.0f; aoo = -1.0f;
+                    behind = Lim<float>::max_v;
+                }
+            }
             if constexpr (BVH != 0) {
                 // Closest hit through the bounding-volume hierarchy instead of the list (the TODO at
                 // main.odin:559).  Per lane, no stack: nodes are in depth-first order for this ray's
@@ -536,8 +611,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     }
                 }
             } else {
-            const F2 dx2 = {rd.x, rd.x}, dy2 = {rd.y, rd.y}, dz2 = {rd.z, rd.z}, nd_o2 = {-d_o, -d_o};
-            const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {a, a};
+            const F2 dx2 = {fd.x, fd.x}, dy2 = {fd.y, fd.y}, dz2 = {fd.z, fd.z}, nd_o2 = {-d_o, -d_o};
+            const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {fa, fa};
             auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
                 const F2 hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
                 const F2 hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
@@ -690,7 +765,11 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         }
         if (ended) {
             // pixel_color += sample_color (main.odin:575)
-            if constexpr (QUEUE) {
+            if constexpr (MIXED) {
+                // the sample's colour goes to its own slot; order_sum_kernel adds the slots in sample order
+                double *dst = static_cast<double *>(P.slabs) + stage_at;
+                dst[0] = color.x; dst[1] = color.y; dst[2] = color.z;
+            } else if constexpr (QUEUE) {
                 unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * 3;
                 atomicAdd(dst + 0, to_q32_32(color.x));
                 atomicAdd(dst + 1, to_q32_32(color.y));
@@ -774,6 +853,8 @@ __global__ void clear_kernel(const ReduceParams P, uint32_t *queue) {
     a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
 }
 
+__global__ void clear_queue_kernel(uint32_t *queue) { *queue = 0u; }
+
 // literal modes: accum[p] += slab_0[p] + slab_1[p] + ... in chunk order
 template <typename Real> __global__ void reduce_kernel(const ReduceParams P) {
     int64_t idx;
@@ -784,6 +865,22 @@ template <typename Real> __global__ void reduce_kernel(const ReduceParams P) {
         const Real *sl = static_cast<const Real *>(P.slabs) + static_cast<int64_t>(c - 1) * P.slab_stride + idx * 3;
         x = x + sl[0]; y = y + sl[1]; z = z + sl[2];
     }
+    base[0] = x; base[1] = y; base[2] = z;
+}
+
+// mixed mode: pixel_color += sample_color in sample order (main.odin:575) over the stored colours of
+// one launch.  Thread gid owns pixel (gid & 63) of owned tile (gid >> 6), the enumeration the render
+// kernel stored under: colour of sample s at staged[(s * stride) + gid * 3].  `chunks` is the number
+// of samples staged; first: the sum starts from zero, otherwise from the accumulator's value.
+__global__ void order_sum_kernel(const ReduceParams P, const int first) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    double *base = static_cast<double *>(P.accum) + idx * 3;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (!first) { x = base[0]; y = base[1]; z = base[2]; }
+    const double *sl = static_cast<const double *>(P.slabs) + gid * 3;
+    for (int c = 0; c < P.chunks; ++c, sl += P.slab_stride) { x = x + sl[0]; y = y + sl[1]; z = z + sl[2]; }
     base[0] = x; base[1] = y; base[2] = z;
 }
 
@@ -882,6 +979,11 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
         if (lds) launch_k(render_kernel<double, false, FETCH_LDS, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(double4), stream, p);
         else launch_k(render_kernel<double, false, FETCH_SCALAR, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(double4), stream, p);
         break;
+    case ARITH_MIXED: {
+        const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (static_cast<int64_t>(p.n_items) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
+        launch_k(render_kernel<double, false, FETCH_SCALAR, true, 0, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        break;
+    }
     case ARITH_F32_LITERAL:
         if (lds) launch_k(render_kernel<float, false, FETCH_LDS, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
         else launch_k(render_kernel<float, false, FETCH_SCALAR, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
@@ -899,8 +1001,19 @@ hipError_t launch_clear(const ReduceParams &p, uint32_t *queue, hipStream_t stre
     return hipGetLastError();
 }
 
+hipError_t launch_clear_queue(uint32_t *queue, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_queue_kernel, dim3(1), dim3(1), 0, stream, queue);
+    return hipGetLastError();
+}
+
+hipError_t launch_order_sum(const ReduceParams &p, bool first, hipStream_t stream) {
+    if (p.map.n_tiles <= 0 || p.chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(order_sum_kernel, pixel_grid(p.map), dim3(256), 0, stream, p, first ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
-    if (p.map.n_tiles <= 0 || p.chunks <= 1 || arith == ARITH_F32_FMA) return hipSuccess;
+    if (p.map.n_tiles <= 0 || p.chunks <= 1 || arith == ARITH_F32_FMA || arith == ARITH_MIXED) return hipSuccess;
     if (arith == ARITH_F64) hipLaunchKernelGGL(reduce_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(reduce_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
@@ -908,7 +1021,7 @@ hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
 
 hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream) {
     if (p.map.n_tiles <= 0) return hipSuccess;
-    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    if (arith == ARITH_F64 || arith == ARITH_MIXED) hipLaunchKernelGGL(finalize_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_q_kernel, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(finalize_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
@@ -916,7 +1029,7 @@ hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t strea
 
 hipError_t launch_finalize_ppm(const PpmParams &p, int arith, hipStream_t stream) {
     if (p.map.n_tiles <= 0) return hipSuccess;
-    if (arith == ARITH_F64) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F64>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    if (arith == ARITH_F64 || arith == ARITH_MIXED) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F64>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_FMA>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_LITERAL>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -30,6 +30,8 @@ class Oracle:
         L.oracle_quantize_rgb8.argtypes = [vp, i64, vp]
         L.oracle_serialize_ppm.argtypes = [vp, i64, i64, vp]
         L.oracle_serialize_ppm.restype = i64
+        L.oracle_mixed_filter.argtypes = [vp, vp, vp, dbl, dbl, vp]
+        L.oracle_mixed_filter.restype = None
         self.L = L
 
     def rng_u32(self, seed, pixel, sample, bounce, draw):
@@ -55,6 +57,14 @@ class Oracle:
     def ray_sphere_intersection(self, precision, o, d, c, radius, t_min, t_max):
         o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))
         return float(self.L.oracle_ray_sphere_intersection(precision, o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, t_min, t_max))
+
+    def mixed_filter(self, o, d, c, radius, reach):
+        """the f32 candidate filter of RT_PRECISION_MIXED for one ray and one sphere ->
+        dict(disc, m, h, behind, in_range, kept)"""
+        o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))
+        out = np.zeros(6, dtype=np.float64)
+        self.L.oracle_mixed_filter(o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, reach, out.ctypes.data)
+        return dict(disc=out[0], m=out[1], h=out[2], behind=out[3], in_range=bool(out[4]), kept=bool(out[5]))
 
     def material_scatter(self, precision, material, ray_o, ray_d, hit_p, hit_n, front_face, seed, pixel, sample, bounce):
         m = np.zeros(1, dtype=rt.MATERIAL_DTYPE)

@@ -1,0 +1,145 @@
+"""The f32 candidate filter of RT_PRECISION_MIXED, on the CPU (oracle restatement of the kernel's filter).
+
+The filter may keep too much, never too little: a sphere it drops must be one that the reference's
+f64 test (main.odin:245-261) cannot report as hit.  Checked two ways: against exact rational
+arithmetic on adversarial single cases, and by auditing every dropped sphere of whole renders.
+"""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+U = Fraction(1, 2 ** 24)
+
+
+def exact_terms(o, d, c, r):
+    """exact h, a*C and discriminant of main.odin:245-249 for f64 inputs (rational arithmetic)"""
+    o, d, c = ([Fraction(float(x)) for x in v] for v in (o, d, c))
+    r = Fraction(float(r))
+    oc = [c[k] - o[k] for k in range(3)]
+    a = sum(x * x for x in d)
+    h = sum(d[k] * oc[k] for k in range(3))
+    cc = sum(x * x for x in oc) - r * r
+    return a, h, cc, h * h - a * cc
+
+
+def norm_upper(v):
+    return Fraction(float(np.sqrt(float(sum(Fraction(float(x)) ** 2 for x in v))))) * Fraction(1000001, 1000000)
+
+
+def cases(rng, n):
+    """rays and spheres chosen to stress the cancellation in the expanded discriminant: far cameras,
+    grazing rays (the line passes the sphere at almost exactly its radius), tiny and huge spheres,
+    short and long directions"""
+    for _ in range(n):
+        scale = 10.0 ** rng.uniform(-3, 4)
+        c = rng.normal(size=3) * scale * rng.choice([0.0, 0.01, 1.0])
+        r = scale * 10.0 ** rng.uniform(-3, 0.5) * rng.choice([1.0, -1.0], p=[0.9, 0.1])
+        o = c + rng.normal(size=3) * abs(r) * 10.0 ** rng.uniform(-1, 3)
+        kind = rng.integers(0, 3)
+        if kind == 0:     # towards a point at distance ~|r| from the centre: grazing
+            t = rng.normal(size=3)
+            t /= np.linalg.norm(t)
+            oc = c - o
+            t -= oc * (t @ oc) / (oc @ oc)
+            t /= np.linalg.norm(t)
+            target = c + t * abs(r) * (1.0 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-9, -2))
+            d = target - o
+        elif kind == 1:   # through the sphere
+            d = (c + rng.normal(size=3) * abs(r) * 0.5) - o
+        else:             # anywhere
+            d = rng.normal(size=3)
+        d = d * 10.0 ** rng.uniform(-4, 4) / max(np.linalg.norm(d), 1e-300)
+        yield o, d, c, r
+
+
+def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
+    rng = np.random.default_rng(2024)
+    worst_low, worst_high, kept, total = None, None, 0, 0
+    for o, d, c, r in cases(rng, 6000):
+        cf = np.float32(c).astype(np.float64)
+        reach = float(np.linalg.norm(cf) + abs(np.float32(r))) * 1.000001
+        f = oracle.mixed_filter(o, d, c, r, reach)
+        a, h, cc, disc = exact_terms(o, d, c, r)
+        if not f["in_range"]:
+            assert f["kept"]
+            continue
+        total += 1
+        kept += f["kept"]
+        S = norm_upper(c) + norm_upper(o) + abs(Fraction(float(r)))
+        unit = U * a * S * S
+        lowered = Fraction(f["disc"])
+        # the lowered f32 discriminant is never below the exact one: the margin (>= 42.7 u a S^2 / 3 ...) exceeds the rounding (<= 34 u a S^2)
+        assert lowered >= disc, (o, d, c, r)
+        gap = (lowered - disc) / unit
+        worst_low = gap if worst_low is None else min(worst_low, gap)
+        worst_high = gap if worst_high is None else max(worst_high, gap)
+        if disc >= 0:
+            assert f["disc"] >= 0
+        # the behind-the-origin rule only fires when the exact signs agree
+        if f["h"] < -f["behind"] and f["m"] > 0:
+            assert h < 0 and cc > 0
+        if disc >= 0 and not (h < 0 and cc > 0):
+            assert f["kept"]
+    print(f"lowered - exact discriminant in units of u*a*S^2: min {float(worst_low):.2f}, max {float(worst_high):.2f}; kept {kept} of {total}")
+    assert worst_low > 0
+
+
+def test_out_of_range_rays_keep_every_sphere(oracle):
+    c, r = (0.0, 0.0, -1.0), 0.5
+    for o, d in (((0.0, 0.0, 0.0), (0.0, 0.0, -1e-25)), ((0.0, 0.0, 0.0), (0.0, 3e21, 0.0)), ((2e7, 0.0, 0.0), (0.0, 1.0, 0.0)),
+                 ((float("nan"), 0.0, 0.0), (0.0, 1.0, 0.0)), ((0.0, 0.0, 0.0), (float("inf"), 1.0, 0.0))):
+        f = oracle.mixed_filter(o, d, c, r, 1.5)
+        assert not f["in_range"] and f["kept"]
+
+
+@pytest.mark.parametrize("name,width,spp", [("dev", 160, 12), ("two", 160, 12), ("final", 240, 4), ("stress", 128, 2)])
+def test_mixed_render_is_the_f64_render_and_no_hit_sphere_is_dropped(rt, oracle, name, width, spp):
+    if name == "stress":
+        cs, sph, mat = rt.build_stress_scene(5, 2000, width)
+    else:
+        cs, sph, mat = {"dev": rt.build_dev_scene, "two": rt.build_two_sphere_scene, "final": lambda w: rt.build_final_scene(1, w)}[name](width)
+    cs.samples_per_pixel = spp
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    a = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=5, threads=8)
+    b = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED, seed=5, threads=8)
+    assert int(b["stats"][6]) == 0                       # spheres dropped by the filter although the f64 test hits them
+    assert np.array_equal(a["image"], b["image"]) and np.array_equal(a["accum"], b["accum"])
+    assert int(a["stats"][0]) == int(b["stats"][0])
+    tests = int(a["stats"][0]) * len(sph)
+    print(f"{name}: the filter keeps {int(b['stats'][5]) / tests:.4%} of {tests} ray/sphere tests")
+    if len(sph) > 100:
+        assert int(b["stats"][5]) * 50 < tests           # and it filters: under 2 % of the tests reach f64
+
+
+def test_far_camera_and_scaled_worlds(rt, oracle):
+    """a camera 5000 units away (|o| >> scene) and worlds scaled to the edges of the filter's range"""
+    cs, sph, mat = rt.build_dev_scene(64)
+    cs.samples_per_pixel = 4
+    for scale in (1.0, 3e-5, 2e4, 1e-7, 1e7):   # the last two leave the range: the filter is not used
+        s2 = sph.copy()
+        s2["center"] *= scale
+        s2["radius"] *= scale
+        c2 = rt.CameraSettings.from_buffer_copy(cs)
+        c2.position = rt.V3(*(np.array(cs.position.tuple()) * scale))
+        c2.focus_distance = cs.focus_distance * scale
+        cam = rt.calculate_camera_render_data(c2)
+        w, h = c2.image_width, c2.image_height
+        a = oracle.render_region(w, h, (0, 0, w, h), cam, s2, mat, precision=rt.PRECISION_F64, seed=9, threads=4)
+        b = oracle.render_region(w, h, (0, 0, w, h), cam, s2, mat, precision=rt.PRECISION_MIXED, seed=9, threads=4)
+        assert int(b["stats"][6]) == 0 and np.array_equal(a["image"], b["image"]), scale
+    far = rt.CameraSettings.from_buffer_copy(cs)
+    eye = np.array([-2000.0, 2000.0, 1000.0]) * 1.7
+    far.position = rt.V3(*eye)
+    right, up, fwd = rt.lookat(tuple(eye), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))
+    far.right, far.up, far.forward = rt.V3(*right), rt.V3(*up), rt.V3(*fwd)
+    far.focus_distance = float(np.linalg.norm(eye - np.array([0.0, 0.0, -1.0])))
+    far.vfov = 0.0002
+    far.depth_of_field_angle = 0.0
+    cam = rt.calculate_camera_render_data(far)
+    w, h = far.image_width, far.image_height
+    a = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=9, threads=4)
+    b = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED, seed=9, threads=4)
+    assert int(b["stats"][6]) == 0 and np.array_equal(a["image"], b["image"])
+    assert int(a["stats"][0]) > w * h * 4 * 1.2      # the camera does see the spheres
