@@ -5,12 +5,18 @@
 
 A step is one full render of the workload: every pixel, every sample, through the C ABI
 (rt_render_accumulate + rt_finalize), with the world and camera already resident in HBM.
-Workload at N=1: the book's final random-spheres scene, 1200x675, 500 spp, depth 50.
-N>1 (one process per GPU, launched by torch.distributed.run): sample split -- rank r traces
-global sample indices [r*500, (r+1)*500) of every pixel, the Q32.32 accumulators are summed with
-an RCCL all-reduce over xGMI and rank 0 finalises a 500*N-spp image (weak scaling: per-GPU
-work is fixed).  `--partition rows` instead deals 8-row strips of ONE 500-spp frame over the
-ranks and gathers them on rank 0 (strong scaling).
+
+N=1: the book's final random-spheres scene, 1200x675, 500 spp, depth 50 (the configuration the
+metric is quoted on).  The timed mode is `--precision` (default mixed: the reference's f64 image
+bit for bit, f32 scan as a conservative filter); the other arithmetic modes are timed beside it
+(`modes` in the output) unless --single-mode.
+
+N>1 (one process per GPU, launched by torch.distributed.run): ONE FIXED frame -- the final scene
+at 3840x2160, 500 spp -- shared by the ranks (strong scaling).  `--partition rows` (default) deals
+8-row strips over the ranks and rank 0 gathers each rank's own rows; `--partition samples` splits
+the 500 samples over the ranks and sums the exact Q32.32 accumulators with an RCCL all-reduce
+(f32 mode only: f64 sums are order-dependent).  `--weak` restores weak scaling (sample partition,
+500 spp per rank, a 500*N-spp frame).
 
 Prints one JSON line on rank 0 with the driver's fields plus `roofline` (FP32 VALU) and
 `cpu_baseline` (the f64 CPU restatement of the reference timed on this host's cores).
@@ -28,6 +34,15 @@ sys.path.insert(0, ROOT)
 F_TEST = 17                 # algorithmic FLOP per ray/sphere test (3 sub, 5+5 dot products, -r^2, h*h-a*c)
 PEAK_FP32_TFLOPS = 157.3    # MI355X vector FP32 peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 GATHER_PEAK_G = 917.8       # --fetch bvh: divergent 16-byte gathers per ns from an L2-resident table, measured by tools/gather_peak
+PMC_SUMMARY = os.path.join("profiles", "round2_pmc_counters.json")
+
+# what each arithmetic mode computes in and which of the spec's parity criteria it meets on the headline frame
+MODES = {
+    "f32": dict(dtype="f32", parity="f32 paths: 79 % of pixels within 1e-4 and 97 % of 8-bit pixels equal to the f64 reference on this frame "
+                                    "(tests assert the floors); meets 1e-4 / 99.9 % on the three-material configuration only"),
+    "mixed": dict(dtype="f64 (f32 candidate filter)", parity="bitwise the f64 reference arithmetic (every pixel; 1e-4 and 99.9 % criteria met)"),
+    "f64": dict(dtype="f64", parity="bitwise the f64 reference arithmetic (every pixel; 1e-4 and 99.9 % criteria met)"),
+}
 
 
 def parse():
@@ -35,29 +50,40 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--width", type=int, default=0, help="image width (default: 1200 at N=1, 3840 at N>1)")
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--scene", default="final", choices=["final", "dev", "stress"])
-    ap.add_argument("--partition", default="samples", choices=["samples", "rows"])
+    ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
+    ap.add_argument("--single-mode", action="store_true", help="N=1: do not time the other arithmetic modes beside --precision")
+    ap.add_argument("--partition", default="rows", choices=["samples", "rows"])
+    ap.add_argument("--weak", action="store_true", help="N>1: weak scaling (sample partition, --spp per rank)")
     ap.add_argument("--fetch", default="auto", choices=["auto", "scalar", "lds", "bvh", "bvh-global"],
                     help="bvh: closest hit through the bounding-volume hierarchy (not the headline: the roofline then counts the tests carried out)")
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--verify", action="store_true", help="after timing, rank 0 re-renders the frame in one rt_render_region call and compares bitwise")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed frame against one rt_render_region call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.width == 0:
+        args.width = 1200 if args.gpus == 1 else 3840
+    if args.weak:
+        args.partition = "samples"
+    if args.fetch.startswith("bvh"):
+        args.precision = "f32"
+    if args.partition == "samples" and args.gpus > 1 and args.precision != "f32":
+        ap.error("--partition samples adds accumulators across ranks, which is exact only for --precision f32 (Q32.32); use --partition rows")
+    return args
 
 
 def measured_traffic(args):
-    """HBM-side bytes of one render_kernel launch of the default workload, from the committed
-    rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile.sh writes
-    TRAFFIC_BYTES_500SPP into the counter summary); None for any other workload."""
-    if (args.scene, args.width, args.spp) != ("final", 1200, 500):
+    """HBM-side bytes of one render launch of the default workload from the committed rocprofv3
+    FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile.sh); not measured in this run."""
+    if (args.scene, args.width, args.spp, args.gpus) != ("final", 1200, 500, 1):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_counters.json")) as f:
-            return float(json.load(f)["TRAFFIC_BYTES_500SPP"])
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+            return float(json.load(f)["TRAFFIC_BYTES_500SPP"][args.precision])
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -102,10 +128,13 @@ class HostStaged:
         self._d.all_reduce(h, op=op)
         t.copy_(h)
 
-    def reduce(self, t, dst, op):
+    def gather(self, t, gather_list, dst):
         h = t.cpu()
-        self._d.reduce(h, dst=dst, op=op)
-        t.copy_(h)
+        hl = [g.cpu() for g in gather_list] if gather_list is not None else None
+        self._d.gather(h, gather_list=hl, dst=dst)
+        if gather_list is not None:
+            for g, x in zip(gather_list, hl):
+                g.copy_(x)
 
     def barrier(self):
         self._d.barrier()
@@ -134,12 +163,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = "single process"
     if world_size > 1:
         if rehearse:
             dist.init_process_group("gloo")
             dist = HostStaged(dist)
+            backend = "gloo on host copies (rehearsal)"
         else:
             dist.init_process_group("nccl", device_id=dev)
+            backend = "RCCL"
 
     if args.scene == "final":
         cs, sph, mat = rt.build_final_scene(1, args.width)
@@ -151,28 +183,16 @@ def main():
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
     fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS, "bvh": rt.FETCH_BVH, "bvh-global": rt.FETCH_BVH_GLOBAL}[args.fetch]
+    precisions = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "f64": rt.PRECISION_F64}
 
     world = rt.World(sph, mat, device=local_rank)
-    accum = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums: exact, so the all-reduce is order-independent
     image = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
-    gathered = torch.zeros_like(image)
+    gathered = torch.zeros_like(image) if world_size > 1 and args.partition == "rows" else image
     stats = torch.zeros(rt.STATS_COUNT, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    by_samples = args.partition == "samples"
-
-    plan = multi_gpu.Plan(args.partition, rank, world_size, args.spp)
-    collect = {"stats": False}
-
-    def trace(buf, **kw):
-        world.render_accumulate(cam, w, h, buf.data_ptr(), seed=1, sphere_fetch=fetch, sample_chunks=args.chunks,
-                                d_stats=stats.data_ptr() if collect["stats"] else 0, stream=stream, **kw)
-
-    def finish(buf, img, total_samples, **kw):
-        world.finalize(buf.data_ptr(), w, h, total_samples, img.data_ptr(), stream=stream, **kw)
-
-    def step(collect_stats=False):
-        collect["stats"] = collect_stats
-        return multi_gpu.render_step(plan, dist, accum, image, gathered, trace, finish)
+    plan = multi_gpu.Plan(args.partition, rank, world_size, args.spp, weak=args.weak)
+    row_gather = multi_gpu.RowGather(plan, image) if world_size > 1 and args.partition == "rows" else None
+    total_spp = plan.total_spp
 
     def fence():
         torch.cuda.synchronize()
@@ -180,73 +200,125 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one counted pass: exact segment count of this rank's share of a step
-    step(collect_stats=True)
-    torch.cuda.synchronize()
-    segments = int(stats[rt.STAT_SEGMENTS].item())
-    samples_rank = int(stats[rt.STAT_SAMPLES].item())
-    wave_iters = int(stats[rt.STAT_WAVE_ITERATIONS].item())
-    bvh_nodes, bvh_tests = int(stats[rt.STAT_BVH_NODES].item()), int(stats[rt.STAT_BVH_TESTS].item())
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    knl = []
-    for _ in range(args.steps):
-        step()
-        # device time of this step's render kernel: HIP events recorded around it on the launch stream
-        knl.append(world.last_kernel_ns())
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_s = sum(knl) / len(knl) * 1e-9
+    def run_mode(mode, steps, warmup):
+        """time `steps` frames in arithmetic mode `mode`; returns the measurements and the buffer holding rank 0's frame"""
+        precision = precisions[mode]
+        # Q32.32 sums (exact, so an all-reduce over ranks is order-independent) or f64 sums in sample order
+        accum = torch.zeros(h, w, 3, dtype=torch.int64 if mode == "f32" else torch.float64, device=dev)
+        collect = {"stats": False}
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    seg_t = torch.tensor([segments, samples_rank], dtype=torch.int64, device=dev)
-    if world_size > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_spp = plan.total_spp
-    samples_step = w * h * total_spp
-    value = samples_step * args.steps / elapsed / 1e6
+        def trace(buf, **kw):
+            world.render_accumulate(cam, w, h, buf.data_ptr(), seed=1, precision=precision, sphere_fetch=fetch, sample_chunks=args.chunks,
+                                    d_stats=stats.data_ptr() if collect["stats"] else 0, stream=stream, **kw)
 
-    if rank == 0:
+        def finish(buf, img, total_samples, **kw):
+            world.finalize(buf.data_ptr(), w, h, total_samples, img.data_ptr(), precision=precision, stream=stream, **kw)
+
+        def step(collect_stats=False):
+            collect["stats"] = collect_stats
+            return multi_gpu.render_step(plan, dist, accum, image, gathered, trace, finish, row_gather)
+
+        # one counted pass: exact segment count of this rank's share of a step
+        stats.zero_()
+        frame = step(collect_stats=True)
+        torch.cuda.synchronize()
+        m = dict(segments=int(stats[rt.STAT_SEGMENTS].item()), samples_rank=int(stats[rt.STAT_SAMPLES].item()),
+                 wave_iters=int(stats[rt.STAT_WAVE_ITERATIONS].item()), bvh_nodes=int(stats[rt.STAT_BVH_NODES].item()),
+                 bvh_tests=int(stats[rt.STAT_BVH_TESTS].item()))
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        knl = []
+        for _ in range(steps):
+            frame = step()
+            # device time of this step's render kernels: HIP events recorded around them on the launch stream
+            knl.append(world.last_kernel_ns())
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        seg_t = torch.tensor([m["segments"], m["samples_rank"]], dtype=torch.int64, device=dev)
+        if world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
+        m["elapsed"] = float(t.item())
+        m["kernel_s"] = sum(knl) / len(knl) * 1e-9
+        m["steps"] = steps
+        m["value"] = w * h * total_spp * steps / m["elapsed"] / 1e6
         # list scan: every segment tests every sphere; hierarchy: the tests the traversal carried out (counted by the kernel)
-        tests_rank = bvh_tests if args.fetch.startswith("bvh") else segments * len(sph)
-        achieved = F_TEST * tests_rank / kernel_s / 1e12
+        m["tests_rank"] = m["bvh_tests"] if args.fetch.startswith("bvh") else m["segments"] * len(sph)
+        m["achieved"] = F_TEST * m["tests_rank"] / m["kernel_s"] / 1e12
+        return m, frame
+
+    def verify(mode, frame):
+        """the timed frame against ONE rt_render_region call over all total_spp samples on rank 0's GPU: bitwise.
+        The mixed mode is checked against the f64 kernel (the reference's arithmetic as written) rather than against itself."""
+        import numpy as np
+        cs.samples_per_pixel = total_spp
+        whole = np.zeros((h, w, 3))
+        against = "f64" if mode == "mixed" else mode
+        # f64 sums follow the chunking: one chunk = strict sample order (what the mixed mode produces); an f64 run is re-rendered with its own chunking
+        chunks = 1 if mode == "mixed" else args.chunks
+        rt.render_region(whole, (0, 0, w, h), rt.calculate_camera_render_data(cs), sph, mat, seed=1, device=local_rank,
+                         precision=precisions[against], sphere_fetch=fetch, sample_chunks=chunks)
+        cs.samples_per_pixel = args.spp
+        return bool(np.array_equal(frame.cpu().numpy(), whole)), f"rt_render_region, {against} kernel, one call, bitwise"
+
+    m, frame = run_mode(args.precision, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        tag = {"f32": "render_kernel<float, fma, scalar fetch, queue>", "mixed": "render_kernel<double, f32 filter, scalar fetch, queue> + order_sum_kernel",
+               "f64": "render_kernel<double, literal, scalar fetch> + reduce_kernel"}[args.precision]
+        partition = "single GPU"
+        if world_size > 1:
+            partition = (f"8-row strips dealt over the ranks, gather of each rank's rows to rank 0 ({backend})" if args.partition == "rows"
+                         else f"sample split, all-reduce of the Q32.32 accumulators ({backend})")
         out = {
-            "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak",
-            "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if by_samples else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} scene ({len(sph)} spheres, seed 1) {w}x{h}, {args.spp} spp per GPU, depth {cs.max_ray_bounces}",
-                       "partition": ("sample split + RCCL all-reduce" if by_samples else "8-row strips + RCCL reduce to rank 0") if world_size > 1 else "single GPU",
+            "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak" if (args.scene, w, total_spp) == ("final", 1200, 500)
+                      else f"Msamples/sec (whole node), {args.scene} scene {w}x{h} {total_spp}spp; % FP32 VALU peak",
+            "value": m["value"], "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": MODES[args.precision]["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.scene} scene ({len(sph)} spheres, seed 1) {w}x{h}, {total_spp} spp per frame, depth {cs.max_ray_bounces}",
+                       "precision": args.precision, "parity": MODES[args.precision]["parity"], "partition": partition,
                        "total_spp": total_spp, "sphere_fetch": args.fetch, "rng": "counter, deterministic, seed 1"},
-            "pct_fp32_peak": 100.0 * achieved / PEAK_FP32_TFLOPS,
-            "segments_per_sample": segments / max(1, samples_rank),
-            "lane_utilization": segments / max(1, 64 * wave_iters),
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+            "pct_fp32_peak": 100.0 * m["achieved"] / PEAK_FP32_TFLOPS,
+            "segments_per_sample": m["segments"] / max(1, m["samples_rank"]),
+            "lane_utilization": m["segments"] / max(1, 64 * m["wave_iters"]),
+            "roofline": {"bound": "valu_fp32", "achieved": m["achieved"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": m["achieved"] / PEAK_FP32_TFLOPS,
                          "traffic": measured_traffic(args) if not args.fetch.startswith("bvh") else None,
-                         "kernel": "render_kernel<float, fma, scalar fetch>", "kernel_ms": kernel_s * 1e3,
-                         "flop_per_test": F_TEST, "sphere_tests_per_launch": tests_rank},
+                         "traffic_source": f"{PMC_SUMMARY} (rocprofv3 --pmc passes over this command; not measured in this run)",
+                         "algorithmic_bytes": w * h * 24 + len(sph) * 16,
+                         "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator/staging stores and atomics are a few % of HBM bandwidth",
+                         "kernel": tag, "kernel_ms": m["kernel_s"] * 1e3, "flop_per_test": F_TEST, "sphere_tests_per_launch": m["tests_rank"]},
         }
         if args.fetch.startswith("bvh"):
             # The traversal is bound by the vector L1's rate of serving per-lane 16-byte gathers that fall into different cache
             # lines: one per box tested, two per sphere tested.  Peak: the L2-resident rate tools/gather_peak measures on this chip.
-            gathers = bvh_nodes + 2 * bvh_tests
-            out["bvh"] = {"boxes_per_segment": bvh_nodes / max(1, segments), "sphere_tests_per_segment": bvh_tests / max(1, segments)}
-            out["roofline"] = {"bound": "vl1d_gather", "achieved": gathers / kernel_s / 1e9, "peak": GATHER_PEAK_G, "unit": "Ggather/s",
-                               "frac": gathers / kernel_s / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>",
-                               "kernel_ms": kernel_s * 1e3, "gathers_per_launch": gathers, "sphere_tests_per_launch": bvh_tests}
+            gathers = m["bvh_nodes"] + 2 * m["bvh_tests"]
+            out["bvh"] = {"boxes_per_segment": m["bvh_nodes"] / max(1, m["segments"]), "sphere_tests_per_segment": m["bvh_tests"] / max(1, m["segments"])}
+            out["roofline"] = {"bound": "vl1d_gather", "achieved": gathers / m["kernel_s"] / 1e9, "peak": GATHER_PEAK_G, "unit": "Ggather/s",
+                               "frac": gathers / m["kernel_s"] / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>",
+                               "kernel_ms": m["kernel_s"] * 1e3, "gathers_per_launch": gathers, "sphere_tests_per_launch": m["bvh_tests"]}
             out["pct_fp32_peak"] = None
-        if args.verify:
-            # the gathered frame against one single-GPU rt_render_region call over all total_spp samples
-            import numpy as np
-            frame = (image if (by_samples or world_size == 1) else gathered).cpu().numpy()
-            cs.samples_per_pixel = total_spp
-            whole = np.zeros((h, w, 3))
-            rt.render_region(whole, (0, 0, w, h), rt.calculate_camera_render_data(cs), sph, mat, seed=1, device=local_rank)
-            out["verified"] = bool(np.array_equal(frame, whole))
+        if not args.no_verify:
+            out["verified"], out["verified_against"] = verify(args.precision, frame)
+    if world_size == 1 and not args.single_mode and not args.fetch.startswith("bvh"):
+        # the other arithmetic modes on the same workload, fewer steps: what each costs and which parity criteria it meets
+        out["modes"] = {args.precision: {"value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": m["kernel_s"] * 1e3,
+                                         "pct_fp32_peak": out["pct_fp32_peak"], "dtype": out["dtype"], "parity": MODES[args.precision]["parity"],
+                                         "verified": out.get("verified")}}
+        for mode in ("f32", "mixed", "f64"):
+            if mode == args.precision:
+                continue
+            steps = max(1, min(args.steps, 3 if mode != "f64" else 2))
+            mm, fr = run_mode(mode, steps, 1 if args.warmup > 0 else 0)
+            entry = {"value": mm["value"], "ms_per_step": mm["elapsed"] / steps * 1e3, "kernel_ms": mm["kernel_s"] * 1e3,
+                     "pct_fp32_peak": 100.0 * mm["achieved"] / PEAK_FP32_TFLOPS, "dtype": MODES[mode]["dtype"], "parity": MODES[mode]["parity"], "steps": steps}
+            if not args.no_verify and mode == "f32":
+                entry["verified"], _ = verify(mode, fr)
+            out["modes"][mode] = entry
+    if rank == 0:
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(rt, cam, sph, mat, w, h, args.cpu_seconds)
         print(json.dumps(out), flush=True)

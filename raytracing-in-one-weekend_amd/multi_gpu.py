@@ -2,14 +2,18 @@
 
 The render path shards without any exchange of rays: pixels and samples are independent because
 the RNG is keyed by (image pixel, global sample index).  Two partitions, as the reference's own
-tile pool is a partition of pixels (main.odin:657-681):
+tile pool is a partition of pixels into disjoint rects (main.odin:657-681):
 
   rows    : 8-row strips of the image dealt round-robin over the ranks (strip s -> rank s % N);
-            each rank finalises its strips and rank 0 gathers the image (a reduce of buffers
-            that are zero outside the owner's strips).
-  samples : rank r traces global samples [r*spp, (r+1)*spp) of every pixel; the Q32.32
-            accumulators are summed with one all-reduce (exact integers, so the result is
-            bitwise the single-GPU image of N*spp samples) and rank 0 finalises.
+            each rank finalises its strips, packs them into a strip-major buffer of its own rows
+            and rank 0 gathers exactly those rows (height/N rows per rank, no reduction).
+  samples : rank r traces its share of the global sample indices of every pixel; the exact
+            accumulators (Q32.32 integers) are summed with one all-reduce, so the result is
+            bitwise the single-GPU image of all the samples, and rank 0 finalises.
+
+Scaling: by default the frame is FIXED (strong scaling: N ranks share one frame of `spp`
+samples per pixel); `weak=True` with the sample partition gives every rank `spp` samples of
+its own, i.e. a frame of N*spp samples per pixel.
 
 `trace` and `finish` are injected so that the partition logic can be exercised on the CPU with
 the gloo backend; on a GPU they are World.render_accumulate / World.finalize.
@@ -27,43 +31,95 @@ class Plan:
     partition: str      # "rows" | "samples"
     rank: int
     world_size: int
-    spp: int            # samples per pixel traced by ONE rank per step
+    spp: int            # samples per pixel: of the frame (strong scaling) or per rank (weak)
+    weak: bool = False  # samples partition only
+
+    def __post_init__(self):
+        if self.partition not in ("rows", "samples"):
+            raise ValueError(self.partition)
+        if self.weak and self.partition != "samples":
+            raise ValueError("weak scaling is the sample partition with per-rank spp")
 
     @property
     def total_spp(self) -> int:
-        return self.spp * self.world_size if self.partition == "samples" else self.spp
+        return self.spp * self.world_size if self.weak else self.spp
+
+    @property
+    def sample_range(self):
+        """(first global sample index, count) this rank traces"""
+        if self.partition == "rows":
+            return 0, self.spp
+        if self.weak:
+            return self.rank * self.spp, self.spp
+        lo = self.rank * self.spp // self.world_size
+        hi = (self.rank + 1) * self.spp // self.world_size
+        return lo, hi - lo
 
     @property
     def sample_begin(self) -> int:
-        return self.rank * self.spp if self.partition == "samples" else 0
+        return self.sample_range[0]
 
     @property
     def strips(self):
         """(strip_rows, strip_index, strip_count) of this rank's pixels"""
         return (STRIP_ROWS, self.rank, self.world_size) if self.partition == "rows" else (STRIP_ROWS, 0, 1)
 
-    def owned_rows(self, height: int):
-        """image rows this rank renders"""
-        rows, index, count = self.strips
-        return [v for v in range(height) if (v // rows) % count == index]
+    def owned_rows(self, height: int, rank: int | None = None):
+        """image rows rank `rank` (default: this one) renders"""
+        if self.partition != "rows":
+            return list(range(height))
+        index = self.rank if rank is None else rank
+        return [v for v in range(height) if (v // STRIP_ROWS) % self.world_size == index]
+
+    def max_owned_rows(self, height: int) -> int:
+        return max(len(self.owned_rows(height, r)) for r in range(self.world_size))
 
 
-def render_step(plan: Plan, dist, accum, image, gathered, trace: Callable, finish: Callable):
-    """One frame.  accum: the rank's accumulators (int64 Q32.32), image: its finalised image
-    (zero outside its strips), gathered: rank 0's output buffer.  Returns the buffer holding the
-    frame on rank 0."""
+class RowGather:
+    """Buffers and index tensors of the row partition's gather, made once per (plan, image shape).
+
+    Every rank packs its own rows of the finalised image, in image order, into `send` (padded to
+    the largest share so all ranks send the same size); rank 0 receives one such buffer per rank
+    and scatters the rows to their places.  Bytes on the wire per rank: its share of the image."""
+
+    def __init__(self, plan: Plan, image):
+        import torch
+        h = image.shape[0]
+        self.plan = plan
+        self.rows = [torch.tensor(plan.owned_rows(h, r), dtype=torch.long, device=image.device) for r in range(plan.world_size)]
+        n_max = plan.max_owned_rows(h)
+        self.send = torch.zeros((n_max,) + tuple(image.shape[1:]), dtype=image.dtype, device=image.device)
+        self.recv = [torch.zeros_like(self.send) for _ in range(plan.world_size)] if plan.rank == 0 else None
+
+    def run(self, dist, image, gathered):
+        import torch
+        mine = self.rows[self.plan.rank]
+        if len(mine):
+            torch.index_select(image, 0, mine, out=self.send[:len(mine)])
+        dist.gather(self.send, gather_list=self.recv, dst=0)
+        if self.plan.rank == 0:
+            for r, rows in enumerate(self.rows):
+                if len(rows):
+                    gathered.index_copy_(0, rows, self.recv[r][:len(rows)])
+        return gathered
+
+
+def render_step(plan: Plan, dist, accum, image, gathered, trace: Callable, finish: Callable, gather: RowGather | None = None):
+    """One frame.  accum: the rank's accumulators, image: its finalised image (only its strips are
+    written), gathered: rank 0's output buffer.  Returns the buffer holding the frame on rank 0."""
     rows, index, count = plan.strips
+    begin, n = plan.sample_range
     if plan.partition == "samples":
-        trace(accum, strip_rows=rows, strip_index=0, strip_count=1, sample_begin=plan.sample_begin, sample_count=plan.spp)
+        trace(accum, strip_rows=rows, strip_index=0, strip_count=1, sample_begin=begin, sample_count=n)
         if plan.world_size > 1:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)
         if plan.rank == 0:
             finish(accum, image, total_samples=plan.total_spp, strip_rows=rows, strip_index=0, strip_count=1)
         return image
-    trace(accum, strip_rows=rows, strip_index=index, strip_count=count, sample_begin=0, sample_count=plan.spp)
+    trace(accum, strip_rows=rows, strip_index=index, strip_count=count, sample_begin=begin, sample_count=n)
     finish(accum, image, total_samples=plan.spp, strip_rows=rows, strip_index=index, strip_count=count)
     if plan.world_size == 1:
         return image
-    gathered.copy_(image)
-    dist.reduce(gathered, dst=0, op=dist.ReduceOp.SUM)
-    return gathered
+    if gather is None:
+        gather = RowGather(plan, image)
+    return gather.run(dist, image, gathered)

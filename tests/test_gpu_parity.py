@@ -540,7 +540,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(monkeypatch, capsys
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8", "--cpu-seconds", "0.5", "--verify"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8", "--cpu-seconds", "0.5"])
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(var, raising=False)
     bench.main()
@@ -552,7 +552,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields(monkeypatch, capsys
                 "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["higher_is_better"] is True
-    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and d["verified"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["verified"] is True
+    assert d["config"]["precision"] in ("f32", "mixed", "f64") and d["dtype"] == {"f32": "f32", "mixed": "f64 (f32 candidate filter)", "f64": "f64"}[d["config"]["precision"]]
+    # the other arithmetic modes are timed beside the headline one, each with the parity criteria it meets
+    assert set(d["modes"]) == {"f32", "mixed", "f64"} and all(m["value"] > 0 and m["parity"] for m in d["modes"].values())
+    assert d["modes"]["f32"]["verified"] is True and d["modes"][d["config"]["precision"]]["verified"] is True
+    assert d["roofline"]["traffic_source"] and d["roofline"]["algorithmic_bytes"] > 0
     r = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.0 < r["frac"] < 1.0 and d["value"] > 0
