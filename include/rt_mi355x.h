@@ -269,6 +269,35 @@ int32_t rt_finalize_ppm(rt_world *world, const void *d_accum, int32_t precision,
  * rt_render_accumulate on it (blocks until they finish); <0 on error */
 int64_t rt_world_last_kernel_ns(rt_world *world);
 
+/*
+ * rt_render_accumulate for callers that cannot allocate device memory (code
+ * under HIP graph capture, serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  Same arguments, same result in d_accum,
+ * but the scratch the kernels need -- the work-queue head, the partial sums
+ * of sample chunks 1.. (RT_PRECISION_F64 / _F32_LITERAL) or the staged sample
+ * colours (RT_PRECISION_MIXED) -- lives in one fixed 32 MiB array per GPU
+ * that the library holds from load until the process ends, instead of in
+ * buffers the world allocates and grows.  The call allocates and frees
+ * nothing.  Limits: (sample_chunks - 1) * width * height * 3 elements of the
+ * precision's accumulator type, or in mixed mode one sample of the call's
+ * pixels (owned 8x8 tiles * 64 * 24 bytes), must fit rt_static_scratch_bytes();
+ * RT_ERR_UNSUPPORTED otherwise (pass a smaller sample_chunks -- 1 needs no
+ * slabs -- or fewer pixels per call), and for RT_FETCH_BVH unless an earlier
+ * rt_render_accumulate on this world has built the hierarchy.
+ * RT_PRECISION_F32 needs only the queue head and is never refused for size.
+ * Every call on a GPU shares that GPU's array: calls that overlap in time on
+ * one GPU race on it (whatever world or stream they use); calls issued one
+ * after the other on one stream do not.
+ */
+int32_t rt_render_accumulate_static(rt_world *world, const rt_camera_render_data *cam,
+                                    int64_t width, int64_t height, rt_rect region,
+                                    int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                                    int64_t sample_begin, int64_t sample_count,
+                                    uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                                    int32_t sample_chunks,
+                                    void *d_accum, uint64_t *d_stats, void *stream);
+/* bytes of that array available for slabs / staged colours */
+int64_t rt_static_scratch_bytes(void);
 
 /* ---- host-side helpers the callers of the path use ------------------------ */
 

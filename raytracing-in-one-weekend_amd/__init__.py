@@ -131,6 +131,10 @@ def lib() -> C.CDLL:
     L.rt_world_destroy.restype = i32
     L.rt_render_accumulate.argtypes = [vp, P(CameraRenderData), i64, i64, Rect, i64, i32, i32, i64, i64, u64, i32, i32, i32, vp, vp, vp]
     L.rt_render_accumulate.restype = i32
+    L.rt_render_accumulate_static.argtypes = L.rt_render_accumulate.argtypes
+    L.rt_render_accumulate_static.restype = i32
+    L.rt_static_scratch_bytes.argtypes = []
+    L.rt_static_scratch_bytes.restype = i64
     L.rt_finalize.argtypes = [vp, vp, i32, i64, i64, Rect, i64, i32, i32, i64, vp, vp, vp]
     L.rt_finalize.restype = i32
     L.rt_finalize_ppm.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, i64, vp, vp]
@@ -168,6 +172,7 @@ EXPORTED_SYMBOLS = (
     "rt_world_create", "rt_world_destroy", "rt_render_accumulate", "rt_finalize", "rt_world_last_kernel_ns", "rt_lookat",
     "rt_calculate_camera_render_data", "rt_build_dev_scene", "rt_build_two_sphere_scene", "rt_build_final_scene",
     "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32", "rt_finalize_ppm", "rt_render_ppm", "rt_bvh_validate",
+    "rt_render_accumulate_static", "rt_static_scratch_bytes",
 )
 
 
@@ -341,11 +346,13 @@ class World:
     def render_accumulate(self, cam: CameraRenderData, width: int, height: int, d_accum: int, *, region=None, strip_rows: int = 8,
                           strip_index: int = 0, strip_count: int = 1, sample_begin: int = 0, sample_count: Optional[int] = None,
                           seed: int = 0, precision: int = PRECISION_F32, sphere_fetch: int = FETCH_AUTO, sample_chunks: int = 0,
-                          d_stats: int = 0, stream: int = 0) -> None:
-        """rt_render_accumulate: d_accum / d_stats / stream are raw device pointers / a hipStream_t."""
+                          d_stats: int = 0, stream: int = 0, static_scratch: bool = False) -> None:
+        """rt_render_accumulate: d_accum / d_stats / stream are raw device pointers / a hipStream_t.
+        static_scratch: rt_render_accumulate_static, the entry point that allocates nothing."""
         region = (0, 0, width, height) if region is None else region
         sample_count = cam.samples_per_pixel if sample_count is None else sample_count
-        _check(lib().rt_render_accumulate(self._h, C.byref(cam), width, height, Rect(*[int(v) for v in region]), strip_rows, strip_index,
+        fn = lib().rt_render_accumulate_static if static_scratch else lib().rt_render_accumulate
+        _check(fn(self._h, C.byref(cam), width, height, Rect(*[int(v) for v in region]), strip_rows, strip_index,
                                           strip_count, sample_begin, sample_count, seed, precision, sphere_fetch, sample_chunks,
                                           d_accum, d_stats or None, stream or None))
 

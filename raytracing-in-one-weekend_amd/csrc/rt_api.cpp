@@ -122,6 +122,7 @@ struct rt_world_s {
     hipEvent_t slabs_done = nullptr;
     hipStream_t slabs_stream = nullptr;
     bool slabs_busy = false;
+    void *static_scratch = nullptr;             // this device's copy of the kernels' static scratch array
     std::mutex mu;
 };
 
@@ -328,6 +329,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         if (e == hipSuccess) e = hipEventCreate(&w->slots[k].ev_end);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w->slabs_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = rtk::static_scratch_address(current, &w->static_scratch); // set-up for rt_render_accumulate_static
     if (e != hipSuccess) {
         rt_world_destroy(w);
         return fail(RT_ERR_DEVICE, "uploading the world failed: %s", hipGetErrorString(e));
@@ -564,6 +566,24 @@ int32_t rt_render_accumulate(rt_world *world, const rt_camera_render_data *cam, 
     return accumulate_impl(world, cam, width, height, region, strip_rows, strip_index, strip_count, sample_begin, sample_count, seed, precision,
                            sphere_fetch, sample_chunks, d_accum, d_stats, stream, ScratchSource{});
 }
+
+int32_t rt_render_accumulate_static(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
+                                    int64_t strip_rows, int32_t strip_index, int32_t strip_count,
+                                    int64_t sample_begin, int64_t sample_count, uint64_t seed, int32_t precision, int32_t sphere_fetch,
+                                    int32_t sample_chunks, void *d_accum, uint64_t *d_stats, void *stream) {
+    if (world == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world is NULL");
+    // the per-device address of the static scratch array was looked up when the world was created
+    if (world->static_scratch == nullptr) return fail(RT_ERR_DEVICE, "the static scratch region of device %d is not available", world->device);
+    ScratchSource src;
+    src.queue = static_cast<uint32_t *>(world->static_scratch);
+    src.work = static_cast<unsigned char *>(world->static_scratch) + rtk::STATIC_SCRATCH_HEAD_BYTES;
+    src.work_bytes = rtk::STATIC_SCRATCH_BYTES - rtk::STATIC_SCRATCH_HEAD_BYTES;
+    src.fixed = true;
+    return accumulate_impl(world, cam, width, height, region, strip_rows, strip_index, strip_count, sample_begin, sample_count, seed, precision,
+                           sphere_fetch, sample_chunks, d_accum, d_stats, stream, src);
+}
+
+int64_t rt_static_scratch_bytes(void) { return static_cast<int64_t>(rtk::STATIC_SCRATCH_BYTES - rtk::STATIC_SCRATCH_HEAD_BYTES); }
 
 int64_t rt_world_last_kernel_ns(rt_world *world) {
     if (world == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "world is NULL");

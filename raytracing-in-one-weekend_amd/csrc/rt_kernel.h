@@ -114,4 +114,12 @@ struct PpmParams {
 };
 hipError_t launch_finalize_ppm(const PpmParams &p, int arith, hipStream_t stream);
 
+// Scratch for callers that cannot allocate: one file-scope device array per GPU, held until the
+// process ends.  Its first STATIC_SCRATCH_HEAD_BYTES hold the work-queue head, the rest chunk slabs
+// or staged sample colours.  static_scratch_address returns the array's address on `device`, which
+// must be the current device the first time it is asked for (the lookup is cached per device).
+constexpr size_t STATIC_SCRATCH_BYTES = static_cast<size_t>(32) << 20;
+constexpr size_t STATIC_SCRATCH_HEAD_BYTES = 256;
+hipError_t static_scratch_address(int device, void **out);
+
 } // namespace rtk

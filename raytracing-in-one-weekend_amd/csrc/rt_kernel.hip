@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <mutex>
 
 namespace rtk {
 
@@ -946,6 +947,30 @@ template <int ARITH> __global__ void finalize_ppm_kernel(const PpmParams P) {
     }
     uint32_t *out = P.text + idx * 3;
     out[0] = ppm_word(g[0], false); out[1] = ppm_word(g[1], false); out[2] = ppm_word(g[2], true);
+}
+
+// ----------------------------------------------------------------------------- static scratch
+// The array's name is a host-side handle, not a device address: each GPU holds its own copy at its
+// own address, looked up once per device and cached; kernels and memsets only ever get that pointer.
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+hipError_t static_scratch_address(int device, void **out) {
+    static std::mutex mu;
+    static void *address[64] = {};
+    if (out == nullptr || device < 0 || device >= 64) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(mu);
+    if (address[device] == nullptr) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice; // the symbol resolves on the current device
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        address[device] = ptr;
+    }
+    *out = address[device];
+    return hipSuccess;
 }
 
 // ----------------------------------------------------------------------------- launchers
