@@ -50,6 +50,14 @@ typedef struct { rt_v3 center; double radius; int64_t material_index; } rt_spher
  * The reference switches all metals at compile time; here it is a material type, so a host built
  * with that flag passes 3 where it passes 1 today.  Same data: albedo, param1 = fuzz. */
 #define RT_MATERIAL_METALLIC_FRESNEL 3
+/* The other two METAL_FRESNEL_KINDs of that block, which the reference does not select (main.odin:332):
+ * kind 0, reflectance_schlick_approximation(cos, r0) with r0 from 1.0/1.27035 (main.odin:334-335, :111-122), and
+ * kind 1, reflectance_hoffman_approximation(cos, r0, 0.5) (main.odin:337-339, :132-144).  The latter is built as the
+ * cited papers define it, not as the reference's text reads: schlick's arguments in their declared order (the text
+ * passes (r0, cos_i), :133) and the factors 7^7/6^6 and 49/6 as real quotients (the text writes 823543 / 46656 and
+ * 49 / 6, which Odin evaluates as the integers 17 and 8, :142).  math.pow(x, 6) is ((x*x)*x)^2. */
+#define RT_MATERIAL_METALLIC_SCHLICK 4
+#define RT_MATERIAL_METALLIC_HOFFMAN 5
 
 /* material :: struct {type: material_type, data: {albedo: v3, param1: f64}}
  * param1 = fuzz for metallic, refractive index for dielectric       main.odin:274-289 (40 B) */
@@ -337,7 +345,8 @@ int32_t rt_build_stress_scene(uint64_t seed, int64_t total_spheres, int64_t imag
  * serialize_ppm (main.odin:791-824): "P3\n{w} {h}\n255\n" then 12 bytes per
  * pixel, each channel u8(256 * min(x, 0.999)) right-aligned in 3 columns.
  * Returns the number of bytes the image needs; writes them if capacity allows
- * (dst may be NULL to query).  No terminating NUL is written.
+ * (dst may be NULL to query).  No terminating NUL is written.  Images of more
+ * than 2^30 pixels: RT_ERR_UNSUPPORTED (here and in rt_render_ppm).
  */
 int64_t rt_serialize_ppm(const rt_v3 *image_data, int64_t width, int64_t height,
                          char *dst, int64_t capacity);
@@ -353,6 +362,14 @@ int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data
                       const rt_sphere *spheres, int64_t n_spheres,
                       const rt_material *materials, int64_t n_materials,
                       const rt_options *opts, char *dst, int64_t capacity);
+/*
+ * rt_render_region, rt_render_tiled and rt_render_ppm keep, per GPU, what a call needed -- the
+ * uploaded world (reused while the caller passes the same spheres and materials, byte for byte), the
+ * accumulator, image and text buffers, a stream -- so that calling them in a loop, as the reference's
+ * benchmark does 100 times (main_test.odin:25-32), costs little more than the kernels.  This frees it
+ * all (every GPU); the next call sets up again.  No counterpart in the reference.
+ */
+int32_t rt_release_cache(void);
 /* the quantiser of main.odin:812-814 alone: rgb8 gets width*height*3 bytes */
 int32_t rt_quantize_rgb8(const rt_v3 *image_data, int64_t n_pixels, uint8_t *rgb8);
 

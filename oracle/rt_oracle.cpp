@@ -358,19 +358,40 @@ template <class Real> inline Real reflectance_fresnel(Real cos_i, Real sin_i, Re
     r_p *= r_p;
     return (r_s + r_p) * Real(0.5);
 }
-/* metallic_proc  main.odin:315-353.  fresnel = false: the USE_METAL_FRESNEL = false branch (:348-350);
- * true: that flag set, with METAL_FRESNEL_KIND 2 as the reference selects it (:326-328, :341-347). */
+/* reflectance_schlick_lazanyi_approximation  main.odin:132-134, with the arguments of the Schlick term in
+ * their declared order (cos_i, r0) -- the reference's text passes (r0, cos_i).  math.pow is core:math (third party,
+ * not in the checkout); for the only exponent used, 6, it is taken as ((x*x)*x)^2. */
+template <class Real> inline Real reflectance_schlick_lazanyi_approximation(Real cos_i, Real r0, Real a) {
+    const Real x = Real(1) - cos_i;
+    const Real x2 = x * x, x3 = x2 * x;
+    return reflectance_schlick_approximation(cos_i, r0) - a * cos_i * (x3 * x3);
+}
+/* reflectance_hoffman_approximation  main.odin:141-144, with 823543/46656 = 7^7/6^6 and 49/6 as real quotients (the
+ * reference's untyped integer constants divide to 17 and 8) */
+template <class Real> inline Real reflectance_hoffman_approximation(Real cos_i, Real r0, Real h) {
+    const Real a = static_cast<Real>(823543.0 / 46656.0) * (r0 - h) + static_cast<Real>(49.0 / 6.0) * (Real(1) - r0);
+    return reflectance_schlick_lazanyi_approximation(cos_i, r0, a);
+}
+/* metallic_proc  main.odin:315-353.  kind < 0: the USE_METAL_FRESNEL = false branch (:348-350); otherwise that flag
+ * set with METAL_FRESNEL_KIND = kind: 2 is what the reference selects (:341-344), 0 (:334-335) and 1 (:337-339) are
+ * its alternatives.  1.0/HARDCODED_REFRACTIVE_INDEX is a constant expression: the exact quotient rounded once. */
 template <class Real, bool FAST = false>
-inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g, bool fresnel) {
+inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g, int kind) {
     Real fuzz = m.param1;
     vec3<Real> dir = normalize_as<Real, FAST>(reflect(ray_in.direction, hit.normal));
     dir = dir + fuzz * random_unit_vector<Real, FAST>(g);
     vec3<Real> attenuation = m.albedo;
-    if (fresnel) {
+    if (kind >= 0) {
         Real cos_theta = dot(-normalize_as<Real, FAST>(ray_in.direction), hit.normal);
         cos_theta = std::min(cos_theta, Real(1));
-        const Real sin_theta = std::sqrt(Real(1) - cos_theta * cos_theta);
-        const Real reflection_factor = reflectance_fresnel<Real>(cos_theta, sin_theta, Real(1), static_cast<Real>(1.27035));
+        Real reflection_factor;
+        if (kind == 2) {
+            const Real sin_theta = std::sqrt(Real(1) - cos_theta * cos_theta);
+            reflection_factor = reflectance_fresnel<Real>(cos_theta, sin_theta, Real(1), static_cast<Real>(1.27035));
+        } else {
+            const Real r0 = reflectance_at_normal_incidence(static_cast<Real>(0.7871846341559413)); /* 1.0/1.27035 */
+            reflection_factor = kind == 0 ? reflectance_schlick_approximation(cos_theta, r0) : reflectance_hoffman_approximation(cos_theta, r0, Real(0.5));
+        }
         const vec3<Real> one{Real(1), Real(1), Real(1)};
         attenuation = m.albedo * (Real(1) - reflection_factor) + one * reflection_factor; /* math.lerp(albedo, 1, t) */
     }
@@ -402,8 +423,10 @@ template <class Real, bool FAST = false>
 inline scatter_result<Real> material_scatter(const material_t<Real> &m, const ray_t<Real> &ray_in, const hit_record<Real> &hit, draw_stream &g) {
     switch (m.type) {
     case RT_MATERIAL_LAMBERTIAN: return lambertian_proc<Real, FAST>(m, ray_in, hit, g);
-    case RT_MATERIAL_METALLIC: return metallic_proc<Real, FAST>(m, ray_in, hit, g, false);
-    case RT_MATERIAL_METALLIC_FRESNEL: return metallic_proc<Real, FAST>(m, ray_in, hit, g, true);
+    case RT_MATERIAL_METALLIC: return metallic_proc<Real, FAST>(m, ray_in, hit, g, -1);
+    case RT_MATERIAL_METALLIC_FRESNEL: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 2);
+    case RT_MATERIAL_METALLIC_SCHLICK: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 0);
+    case RT_MATERIAL_METALLIC_HOFFMAN: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 1);
     default: return dielectric_proc<Real, FAST>(m, ray_in, hit, g);
     }
 }

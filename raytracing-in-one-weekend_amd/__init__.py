@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
     L.rt_serialize_ppm.restype = i64
     L.rt_quantize_rgb8.argtypes = [vp, i64, vp]
     L.rt_quantize_rgb8.restype = i32
+    L.rt_release_cache.argtypes = []
+    L.rt_release_cache.restype = i32
     L.rt_rng_u32.argtypes = [u64, u32, u32, u32, u32]
     L.rt_rng_u32.restype = u32
     _lib = L
@@ -172,7 +174,7 @@ EXPORTED_SYMBOLS = (
     "rt_world_create", "rt_world_destroy", "rt_render_accumulate", "rt_finalize", "rt_world_last_kernel_ns", "rt_lookat",
     "rt_calculate_camera_render_data", "rt_build_dev_scene", "rt_build_two_sphere_scene", "rt_build_final_scene",
     "rt_build_stress_scene", "rt_serialize_ppm", "rt_quantize_rgb8", "rt_rng_u32", "rt_finalize_ppm", "rt_render_ppm", "rt_bvh_validate",
-    "rt_render_accumulate_static", "rt_static_scratch_bytes",
+    "rt_render_accumulate_static", "rt_static_scratch_bytes", "rt_release_cache",
 )
 
 
@@ -279,6 +281,11 @@ def quantize_rgb8(image: np.ndarray) -> np.ndarray:
     out = np.empty(image.shape, dtype=np.uint8)
     _check(lib().rt_quantize_rgb8(image.ctypes.data, image.size // 3, out.ctypes.data))
     return out
+
+
+def release_cache() -> None:
+    """free what the one-shot entry points keep per GPU between calls (world, buffers, stream)"""
+    _check(lib().rt_release_cache())
 
 
 def rng_u32(seed: int, pixel: int, sample: int, bounce: int, draw: int) -> int:

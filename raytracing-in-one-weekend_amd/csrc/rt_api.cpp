@@ -135,9 +135,9 @@ int32_t validate_scene(const rt_sphere *spheres, int64_t n_spheres, const rt_mat
     if (n_spheres > (1 << 24) || n_materials > (1 << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 spheres or materials");
     for (int64_t i = 0; i < n_materials; ++i) {
         const rt_material &m = materials[i];
-        if (m.type < RT_MATERIAL_LAMBERTIAN || m.type > RT_MATERIAL_METALLIC_FRESNEL) return fail(RT_ERR_INVALID_SCENE, "material %lld has unknown type %lld", (long long)i, (long long)m.type);
+        if (m.type < RT_MATERIAL_LAMBERTIAN || m.type > RT_MATERIAL_METALLIC_HOFFMAN) return fail(RT_ERR_INVALID_SCENE, "material %lld has unknown type %lld", (long long)i, (long long)m.type);
         // make_metallic_data asserts 0 <= fuzz <= 1 (main.odin:280)
-        if ((m.type == RT_MATERIAL_METALLIC || m.type == RT_MATERIAL_METALLIC_FRESNEL) && !(0.0 <= m.param1 && m.param1 <= 1.0)) return fail(RT_ERR_INVALID_SCENE, "metallic material %lld has fuzz %g outside [0, 1]", (long long)i, m.param1);
+        if ((m.type == RT_MATERIAL_METALLIC || m.type >= RT_MATERIAL_METALLIC_FRESNEL) && !(0.0 <= m.param1 && m.param1 <= 1.0)) return fail(RT_ERR_INVALID_SCENE, "metallic material %lld has fuzz %g outside [0, 1]", (long long)i, m.param1);
         if (m.type == RT_MATERIAL_DIELECTRIC && !(m.param1 > 0.0) ) return fail(RT_ERR_INVALID_SCENE, "dielectric material %lld has refractive index %g <= 0", (long long)i, m.param1);
     }
     for (int64_t i = 0; i < n_spheres; ++i) {
@@ -651,6 +651,40 @@ int32_t rt_finalize_ppm(rt_world *world, const void *d_accum, int32_t precision,
 
 namespace {
 
+// What a one-shot call needs on a device, kept between calls: the reference's benchmark calls
+// render_region 100 times on one world (main_test.odin:25-32), and creating the world, the buffers
+// and the stream anew each time would cost more than the kernels.  One entry per device ordinal,
+// used under that device's mutex; the world is reused when the caller's spheres and materials are
+// byte for byte those it was made from.  rt_release_cache frees everything.
+struct DeviceCache {
+    rt_world *world = nullptr;
+    std::vector<unsigned char> scene;   // the spheres' bytes followed by the materials'
+    int64_t n_spheres = -1, n_materials = -1;
+    void *accum = nullptr; size_t accum_bytes = 0;
+    void *image = nullptr; size_t image_bytes = 0;
+    void *linear = nullptr; size_t linear_bytes = 0;
+    void *text = nullptr; size_t text_bytes = 0;
+    uint64_t *stats = nullptr;
+    hipStream_t stream = nullptr;
+};
+DeviceCache g_cache[MAX_DEVICES];
+
+hipError_t ensure_bytes(void **buf, size_t *have, size_t need) {
+    if (*buf != nullptr && *have >= need) return hipSuccess;
+    if (*buf != nullptr) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
+    hipError_t e = hipMalloc(buf, std::max<size_t>(need, 64));
+    if (e == hipSuccess) *have = need;
+    return e;
+}
+
+void release_cache_entry(DeviceCache &c) {
+    if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    rt_world_destroy(c.world); c.world = nullptr;
+    c.scene.clear(); c.n_spheres = c.n_materials = -1;
+    for (void **b : {&c.accum, &c.image, &c.linear, &c.text, reinterpret_cast<void **>(&c.stats)}) if (*b) { (void)hipFree(*b); *b = nullptr; }
+    c.accum_bytes = c.image_bytes = c.linear_bytes = c.text_bytes = 0;
+}
+
 // rt_render_region and rt_render_ppm: host buffers in, host buffers out.  Exactly one of
 // image_data (f64 image of `region`) and ppm_body (12 bytes of text per pixel of the whole
 // image) is non-NULL.
@@ -683,6 +717,7 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     const char *wrap_env = std::getenv("RT_MI355X_WRAP_DEVICES");
     const bool wrap = wrap_env != nullptr && wrap_env[0] == '1' && n_dev > 0;
     if (!wrap && (first >= n_dev || first + count > n_dev)) return fail(RT_ERR_DEVICE, "devices [%d, %d) requested, %d visible", first, first + count, n_dev);
+    if (n_dev > MAX_DEVICES || count > MAX_DEVICES) return fail(RT_ERR_UNSUPPORTED, "more than %d devices", MAX_DEVICES);
     auto ordinal = [&](int g) { return wrap ? (first + g) % n_dev : first + g; };
 
     uint64_t seed = o.seed;
@@ -692,7 +727,8 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     }
 
     struct PerDevice {
-        int device = 0; rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr; char *text = nullptr;
+        int device = 0; bool cached = false;
+        rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr; char *text = nullptr;
         uint64_t *stats = nullptr; hipStream_t stream = nullptr;
     };
     std::vector<PerDevice> devs(count);
@@ -702,7 +738,9 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     auto cleanup = [&]() {
         for (auto &d : devs) {
             (void)hipSetDevice(d.device);
-            if (d.stream) { (void)hipStreamSynchronize(d.stream); (void)hipStreamDestroy(d.stream); }
+            if (d.stream) (void)hipStreamSynchronize(d.stream);
+            if (d.cached) continue; // kept for the next call
+            if (d.stream) (void)hipStreamDestroy(d.stream);
             if (d.accum) (void)hipFree(d.accum);
             if (d.image) (void)hipFree(d.image);
             if (d.text) (void)hipFree(d.text);
@@ -721,21 +759,60 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
         used.erase(std::unique(used.begin(), used.end()), used.end());
         for (int dev : used) locks.emplace_back(device_mutex(dev)); // ascending order: no lock-order inversion between calls
     }
+    const size_t scene_bytes = (static_cast<size_t>(n_spheres) * sizeof(rt_sphere)) + static_cast<size_t>(n_materials) * sizeof(rt_material);
+    auto same_scene = [&](const DeviceCache &c) {
+        if (c.world == nullptr || c.n_spheres != n_spheres || c.n_materials != n_materials || c.scene.size() != scene_bytes) return false;
+        const size_t sb = static_cast<size_t>(n_spheres) * sizeof(rt_sphere);
+        return (sb == 0 || std::memcmp(c.scene.data(), spheres, sb) == 0) &&
+               (scene_bytes == sb || std::memcmp(c.scene.data() + sb, materials, scene_bytes - sb) == 0);
+    };
 
     // launch everything on every device, then collect
+    bool cache_taken[MAX_DEVICES] = {};
+#ifdef RT_DIAG_NO_CACHE
+    for (bool &t : cache_taken) t = true; // diagnostic build: every call sets up and tears down, to measure what the cache saves
+#endif
     for (int g = 0; g < count && result == RT_OK; ++g) {
         PerDevice &d = devs[g];
         d.device = ordinal(g);
         hipError_t e = hipSetDevice(d.device);
-        if (e == hipSuccess) e = hipStreamCreate(&d.stream);
-        if (e == hipSuccess) e = hipMalloc(&d.accum, n_px * 3 * accum_size(o.precision));
-        if (e == hipSuccess && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.image), n_px * 3 * sizeof(double));
-        if (e == hipSuccess && ppm_body) e = hipMalloc(reinterpret_cast<void **>(&d.text), n_px * 12);
-        if (e == hipSuccess && o.linear_out && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.linear), n_px * 3 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.stats), sizeof(uint64_t) * RT_STATS_COUNT);
-        if (e == hipSuccess) e = hipMemsetAsync(d.stats, 0, sizeof(uint64_t) * RT_STATS_COUNT, d.stream);
+        const size_t accum_need = n_px * 3 * accum_size(o.precision), image_need = n_px * 3 * sizeof(double), text_need = n_px * 12;
+        if (e == hipSuccess && !cache_taken[d.device]) {
+            // the first strip set on this device uses (and fills) the device's cache
+            cache_taken[d.device] = true;
+            d.cached = true;
+            DeviceCache &c = g_cache[d.device];
+            if (c.stream == nullptr) e = hipStreamCreate(&c.stream);
+            if (e == hipSuccess) e = ensure_bytes(&c.accum, &c.accum_bytes, accum_need);
+            if (e == hipSuccess && image_data) e = ensure_bytes(&c.image, &c.image_bytes, image_need);
+            if (e == hipSuccess && ppm_body) e = ensure_bytes(&c.text, &c.text_bytes, text_need);
+            if (e == hipSuccess && o.linear_out && image_data) e = ensure_bytes(&c.linear, &c.linear_bytes, image_need);
+            if (e == hipSuccess && c.stats == nullptr) e = hipMalloc(reinterpret_cast<void **>(&c.stats), sizeof(uint64_t) * RT_STATS_COUNT);
+            d.stream = c.stream; d.accum = c.accum; d.image = static_cast<double *>(c.image); d.text = static_cast<char *>(c.text);
+            d.linear = (o.linear_out && image_data) ? static_cast<double *>(c.linear) : nullptr; d.stats = c.stats;
+            if (e == hipSuccess && !same_scene(c)) {
+                rt_world_destroy(c.world); c.world = nullptr; c.n_spheres = c.n_materials = -1;
+                result = rt_world_create(spheres, n_spheres, materials, n_materials, d.device, &c.world);
+                if (result == RT_OK) {
+                    c.scene.resize(scene_bytes);
+                    const size_t sb = static_cast<size_t>(n_spheres) * sizeof(rt_sphere);
+                    if (sb) std::memcpy(c.scene.data(), spheres, sb);
+                    if (scene_bytes > sb) std::memcpy(c.scene.data() + sb, materials, scene_bytes - sb);
+                    c.n_spheres = n_spheres; c.n_materials = n_materials;
+                }
+            }
+            d.world = c.world;
+        } else if (e == hipSuccess) {
+            e = hipStreamCreate(&d.stream);
+            if (e == hipSuccess) e = hipMalloc(&d.accum, std::max<size_t>(accum_need, 64));
+            if (e == hipSuccess && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.image), image_need);
+            if (e == hipSuccess && ppm_body) e = hipMalloc(reinterpret_cast<void **>(&d.text), text_need);
+            if (e == hipSuccess && o.linear_out && image_data) e = hipMalloc(reinterpret_cast<void **>(&d.linear), image_need);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.stats), sizeof(uint64_t) * RT_STATS_COUNT);
+            if (e == hipSuccess) result = rt_world_create(spheres, n_spheres, materials, n_materials, d.device, &d.world);
+        }
+        if (e == hipSuccess && result == RT_OK) e = hipMemsetAsync(d.stats, 0, sizeof(uint64_t) * RT_STATS_COUNT, d.stream);
         if (e != hipSuccess) { result = fail(RT_ERR_DEVICE, "device %d set-up failed: %s", d.device, hipGetErrorString(e)); break; }
-        result = rt_world_create(spheres, n_spheres, materials, n_materials, d.device, &d.world);
         if (result != RT_OK) break;
         result = rt_render_accumulate(d.world, cam, width, height, region, strip_rows, g, count, 0, cam->samples_per_pixel, seed, o.precision,
                                       o.sphere_fetch, o.sample_chunks, d.accum, d.stats, d.stream);
@@ -806,6 +883,8 @@ int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data
                       const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
                       const rt_options *opts, char *dst, int64_t capacity) {
     if (width < 0 || height < 0) return fail(RT_ERR_INVALID_ARGUMENT, "negative image size");
+    // the limit of plan_work, applied before any size is computed from the arguments
+    if (width > (int64_t(1) << 30) || height > (int64_t(1) << 30) || width * height > (int64_t(1) << 30)) return fail(RT_ERR_UNSUPPORTED, "image of %lld x %lld pixels exceeds 2^30", (long long)width, (long long)height);
     char header[64];
     const int header_len = std::snprintf(header, sizeof header, "P3\n%lld %lld\n255\n", (long long)width, (long long)height);
     const int64_t need = header_len + width * height * 12;
@@ -816,6 +895,22 @@ int64_t rt_render_ppm(int64_t width, int64_t height, const rt_camera_render_data
     const rt_rect whole = {0, 0, width, height};
     const int32_t rc = render_to_host(nullptr, dst + header_len, width, height, whole, cam, spheres, n_spheres, materials, n_materials, opts);
     return rc == RT_OK ? need : rc;
+}
+
+int32_t rt_release_cache(void) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) return RT_OK; // no device: nothing was ever cached
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int dev = 0; dev < std::min(n_dev, MAX_DEVICES); ++dev) {
+        std::lock_guard<std::mutex> lock(device_mutex(dev));
+        DeviceCache &c = g_cache[dev];
+        if (c.world == nullptr && c.stream == nullptr && c.accum == nullptr) continue;
+        (void)hipSetDevice(dev);
+        release_cache_entry(c);
+    }
+    (void)hipSetDevice(prev);
+    return RT_OK;
 }
 
 int32_t rt_bvh_validate(const rt_sphere *spheres, int64_t n_spheres, int64_t *n_nodes, int64_t *max_leaf) {

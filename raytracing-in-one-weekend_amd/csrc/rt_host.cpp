@@ -221,6 +221,8 @@ int32_t rt_quantize_rgb8(const rt_v3 *image_data, int64_t n_pixels, uint8_t *rgb
 // serialize_ppm  main.odin:791-824
 int64_t rt_serialize_ppm(const rt_v3 *image_data, int64_t width, int64_t height, char *dst, int64_t capacity) {
     if (width < 0 || height < 0) return RT_ERR_INVALID_ARGUMENT;
+    // the image size limit of the render entry points, applied before any size is computed from the arguments
+    if (width > (int64_t(1) << 30) || height > (int64_t(1) << 30) || width * height > (int64_t(1) << 30)) return RT_ERR_UNSUPPORTED;
     char header[64];
     const int header_len = std::snprintf(header, sizeof header, "P3\n%lld %lld\n255\n", (long long)width, (long long)height);
     const int64_t need = header_len + width * height * 12;

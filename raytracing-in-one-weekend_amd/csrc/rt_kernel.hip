@@ -560,6 +560,12 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
                 const float ax = P.bvh_step[0] * ix, ay = P.bvh_step[1] * iy, az = P.bvh_step[2] * iz;
                 const float bx = (P.bvh_origin[0] - ro.x) * ix, by = (P.bvh_origin[1] - ro.y) * iy, bz = (P.bvh_origin[2] - ro.z) * iz;
+                // The slab parameters below are off by at most 4 u (|q A| + |B|) each (u = 2^-24: the reciprocal, the two
+                // products, the difference origin - o and the fused operation), which for an origin far from the scene
+                // exceeds what the padding of the boxes absorbs.  The interval test is widened by 2^-20 of the largest
+                // |q| |A| + |B| over the axes the ray moves along, so no box whose exact test succeeds is skipped.
+                auto slack_of = [](const float a, const float b) { const float e = fma_rn(65535.0f, abs_rn(a), abs_rn(b)); return (e < Lim<float>::max_v) ? e : 0.0f; };
+                const float box_slack = 9.5367431640625e-07f * max_num(max_num(slack_of(ax, bx), slack_of(ay, by)), slack_of(az, bz));
                 // does the segment [0, closest] meet the box {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16}?
                 // A NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box.
                 auto meets_box = [&](const uint32_t w0, const uint32_t w1, const uint32_t w2) -> bool {
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     const float tz0 = fma_rn(static_cast<float>(w1 & 0xffffu), az, bz), tz1 = fma_rn(static_cast<float>(w2 >> 16), az, bz);
                     const float t_in = max_num(max_num(min_num(tx0, tx1), min_num(ty0, ty1)), max_num(min_num(tz0, tz1), 0.0f));
                     const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), closest));
-                    return t_in <= t_out;
+                    return t_in <= t_out + box_slack;
                 };
                 auto test_leaf = [&](const int first, const int count) {
 #ifdef RT_DIAG_BVH_LEAF
@@ -721,7 +727,26 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
                     dir = normalize<Real, FMA>(reflect(rd, nrm));
                     dir = dir + m.w * ruv;
-                    if (mtype == 3) {
+                    if (mtype >= 4) {
+                        // USE_METAL_FRESNEL with METAL_FRESNEL_KIND 0 (type 4: Schlick, main.odin:334-335, :111-122) or 1
+                        // (type 5: Hoffman, :337-339, :132-144, with schlick's arguments in their declared order and the two
+                        // quotients as real numbers, 7^7/6^6 and 49/6, where the reference's text swaps the former and
+                        // divides integers in the latter).  1.0/1.27035 is a constant expression there, i.e. the exact
+                        // quotient rounded once; math.pow(x, 6) is taken as ((x*x)*x)^2.
+                        Real cos_theta = dot(-normalize<Real, FMA>(rd), nrm);
+                        cos_theta = min_std(cos_theta, Real(1));
+                        const Real rel = static_cast<Real>(0.7871846341559413);
+                        Real r0 = (Real(1) - rel) / (Real(1) + rel);
+                        r0 *= r0;
+                        const Real qq = Real(1) - cos_theta;
+                        Real refl = r0 + (Real(1) - r0) * qq * qq * qq * qq * qq;
+                        if (mtype == 5) {
+                            const Real aa = static_cast<Real>(823543.0 / 46656.0) * (r0 - Real(0.5)) + static_cast<Real>(49.0 / 6.0) * (Real(1) - r0);
+                            const Real q2 = qq * qq, q3 = q2 * qq;
+                            refl = refl - aa * cos_theta * (q3 * q3);
+                        }
+                        atten = atten * (Real(1) - refl) + V3<Real>{Real(1), Real(1), Real(1)} * refl;
+                    } else if (mtype == 3) {
                         // USE_METAL_FRESNEL, METAL_FRESNEL_KIND 2 (main.odin:326-328, :341-347, :84-109)
                         Real cos_theta = dot(-normalize<Real, FMA>(rd), nrm);
                         cos_theta = min_std(cos_theta, Real(1));

@@ -7,6 +7,7 @@ reference's f64, so agreement with the C++ oracle is expected bit for bit.
 Slow: use for images of a few hundred pixel-samples only.
 """
 import math
+from fractions import Fraction
 
 M32 = 0xFFFFFFFF
 F64_EPSILON = 2.220446049250313e-16
@@ -183,14 +184,26 @@ def material_scatter(material, ro, rd, hit_p, hit_n, front_face, gen):
         if is_near_zero(out):
             out = hit_n
         return (hit_p, out), albedo, True
-    if mtype in (1, 3):
+    if mtype in (1, 3, 4, 5):
         out = normalize(reflect(rd, hit_n))
         out = vadd(out, smul(param1, random_unit_vector(gen)))
         attenuation = albedo
-        if mtype == 3:  # USE_METAL_FRESNEL with METAL_FRESNEL_KIND 2 (main.odin:326-328, :341-347)
+        if mtype >= 3:  # USE_METAL_FRESNEL (main.odin:324-347): type 3 = METAL_FRESNEL_KIND 2, 4 = kind 0, 5 = kind 1
             cos_theta = min(dot(neg(normalize(rd)), hit_n), 1.0)
-            sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
-            t = reflectance_fresnel(cos_theta, sin_theta, 1.0, 1.27035)
+            if mtype == 3:
+                sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
+                t = reflectance_fresnel(cos_theta, sin_theta, 1.0, 1.27035)
+            else:
+                rel = float(Fraction(100000, 127035))      # 1.0/1.27035 as a constant expression: exact quotient, rounded once
+                r0 = (1.0 - rel) / (1.0 + rel)
+                r0 *= r0
+                x = 1.0 - cos_theta
+                t = r0 + (1.0 - r0) * x * x * x * x * x    # reflectance_schlick_approximation(cos_theta, r0), main.odin:119-122
+                if mtype == 5:                              # Hoffman (main.odin:132-144), arguments and constants as the papers have them
+                    a = (823543.0 / 46656.0) * (r0 - 0.5) + (49.0 / 6.0) * (1.0 - r0)
+                    x2 = x * x
+                    x3 = x2 * x
+                    t = t - a * cos_theta * (x3 * x3)
             attenuation = vadd(smul(1.0 - t, albedo), smul(t, (1.0, 1.0, 1.0)))  # math.lerp(albedo, 1, t)
         return (hit_p, out), attenuation, dot(out, hit_n) > 0
     ri = param1

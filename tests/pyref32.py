@@ -200,11 +200,24 @@ def material_scatter(material, rd, hit_p, hit_n, front_face, g):
         if all(abs(x) <= F(1e-8) for x in out):
             out = hit_n
         return (hit_p, out), albedo, True
-    if mtype in (1, 3):
+    if mtype in (1, 3, 4, 5):
         out = normalize(reflect(rd, hit_n))
         out = vadd(out, smul(param1, random_unit_vector(g)))
         attenuation = albedo
-        if mtype == 3:  # main.odin:326-328, :341-347, :84-109
+        if mtype >= 4:  # METAL_FRESNEL_KIND 0 (Schlick) and 1 (Hoffman, as the papers define it): main.odin:333-339, :111-144
+            cos_theta = min(dot(vneg(normalize(rd)), hit_n), ONE)
+            rel = F(0.7871846341559413)
+            r0 = (ONE - rel) / (ONE + rel)
+            r0 = r0 * r0
+            x = ONE - cos_theta
+            t = r0 + (ONE - r0) * x * x * x * x * x
+            if mtype == 5:
+                a = F(823543.0 / 46656.0) * (r0 - HALF) + F(49.0 / 6.0) * (ONE - r0)
+                x2 = x * x
+                x3 = x2 * x
+                t = t - a * cos_theta * (x3 * x3)
+            attenuation = vadd(smul(ONE - t, albedo), smul(t, (ONE, ONE, ONE)))
+        elif mtype == 3:  # main.odin:326-328, :341-347, :84-109
             cos_theta = min(dot(vneg(normalize(rd)), hit_n), ONE)
             sin_theta = np.sqrt(ONE - cos_theta * cos_theta)
             n1, n2 = ONE, F(1.27035)

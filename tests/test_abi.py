@@ -64,6 +64,13 @@ def test_argument_validation_needs_no_device(rt):
     assert L.rt_render_region(None, 32, 18, rt.Rect(0, 0, 32, 18), C.byref(cam), sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), None) == rt.RT_ERR_INVALID_ARGUMENT
     assert L.rt_world_create(sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), 0, None) == rt.RT_ERR_INVALID_ARGUMENT
     assert L.rt_world_destroy(None) == rt.RT_OK
+    # sizes are validated before anything is computed from them: no overflowed byte count is ever returned as a size
+    huge = 1 << 40
+    assert L.rt_render_ppm(huge, huge, C.byref(cam), sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), None, None, 0) == rt.RT_ERR_UNSUPPORTED
+    assert L.rt_render_ppm(1 << 20, 1 << 20, C.byref(cam), sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), None, None, 0) == rt.RT_ERR_UNSUPPORTED
+    assert L.rt_serialize_ppm(None, huge, huge, None, 0) == rt.RT_ERR_UNSUPPORTED
+    assert L.rt_serialize_ppm(None, 1 << 15, 1 << 15, None, 0) == len(b"P3\n32768 32768\n255\n") + 12 * (1 << 30)   # the largest image: a size query
+    assert L.rt_release_cache() == rt.RT_OK   # nothing cached, no device needed
     # an empty region is a successful no-op that needs no device either
     assert L.rt_render_region(img.ctypes.data, 32, 18, rt.Rect(3, 3, 3, 9), C.byref(cam), sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), None) == rt.RT_OK
     assert np.all(img == 0)

@@ -364,26 +364,28 @@ def test_bvh_edge_cases(rt):
         gpu_render(rt, cs, cam, sph, mat, seed=2, sphere_fetch=rt.FETCH_BVH, precision=rt.PRECISION_F64)
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2])
-def test_metal_fresnel_material_type(rt, oracle, precision):
-    """RT_MATERIAL_METALLIC_FRESNEL (the reference's USE_METAL_FRESNEL build, main.odin:324-347):
-    GPU against the oracle, bitwise, with every metal of the scene switched to it."""
+@pytest.mark.parametrize("mtype", [3, 4, 5])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3])
+def test_metal_fresnel_material_type(rt, oracle, precision, mtype):
+    """RT_MATERIAL_METALLIC_FRESNEL / _SCHLICK / _HOFFMAN (the reference's USE_METAL_FRESNEL build with
+    METAL_FRESNEL_KIND 2 / 0 / 1, main.odin:324-347): GPU against the oracle, bitwise, with every metal of the
+    scene switched to it (the mixed mode against the f64 oracle)."""
     for name, width, spp in (("dev", 64, 8), ("final", 96, 4)):
         cs, cam, sph, mat = scene(rt, name, width, spp)
         mat = mat.copy()
         metals = mat["type"] == 1
         assert metals.any()
-        mat["type"][metals] = 3
+        mat["type"][metals] = mtype
         w, h = cs.image_width, cs.image_height
         image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=6, precision=precision, sample_chunks=1)
-        ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=precision, seed=6)
+        ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1 if precision == 3 else precision, seed=6)
         assert np.array_equal(image, ref["image"]) and np.array_equal(linear, ref["linear"])
         assert int(stats[0]) == int(ref["stats"][0])
         if precision == 0:
             bvh, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=6, sphere_fetch=rt.FETCH_BVH)
             assert np.array_equal(bvh, image)
     bad = mat.copy()
-    bad["type"][0] = 4
+    bad["type"][0] = 6
     with pytest.raises(rt.RtError):
         gpu_render(rt, cs, cam, sph, bad, seed=6)
 
@@ -643,6 +645,24 @@ def test_mixed_outside_the_filter_range_and_far_camera(rt, oracle):
     ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=9, threads=4)
     image, _, stats = gpu_render(rt, far, cam, sph, mat, seed=9, precision=rt.PRECISION_MIXED)
     assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0])
+    # the hierarchy from that distance (and ten times farther): its slab arithmetic loses absolute accuracy with the
+    # distance of the origin, the traversal's test is widened accordingly, and the image stays the list scan's
+    for scale in (1.0, 10.0, 300.0):
+        cfar = rt.CameraSettings.from_buffer_copy(far)
+        cfar.position = rt.V3(*(eye * scale))
+        cfar.focus_distance = float(np.linalg.norm(eye * scale - np.array([0.0, 0.0, -1.0])))
+        right, up, fwd = rt.lookat(tuple(eye * scale), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))
+        cfar.right, cfar.up, cfar.forward = rt.V3(*right), rt.V3(*up), rt.V3(*fwd)
+        cfar.vfov = 0.0002 / scale
+        camf = rt.calculate_camera_render_data(cfar)
+        a, _, st_a = gpu_render(rt, cfar, camf, sph, mat, seed=9)
+        for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
+            b, _, st_b = gpu_render(rt, cfar, camf, sph, mat, seed=9, sphere_fetch=fetch)
+            assert np.array_equal(a, b) and int(st_a[0]) == int(st_b[0]), (scale, fetch)
+        fin_cs, fin_cam, fin_sph, fin_mat = scene(rt, "final", 64, 2)
+        a, _, _ = gpu_render(rt, cfar, camf, fin_sph, fin_mat, seed=9)
+        b, _, _ = gpu_render(rt, cfar, camf, fin_sph, fin_mat, seed=9, sphere_fetch=rt.FETCH_BVH)
+        assert np.array_equal(a, b), scale
 
 
 def test_mixed_headline_frame_against_f64_kernel_and_f32_floor(rt, oracle):
@@ -764,3 +784,37 @@ def test_two_streams_on_one_world(rt, precision, chunks):
     assert all(torch.equal(o, want_b) for o in outs)
     assert world.last_kernel_ns() > 0
     world.close()
+
+
+def test_one_shot_calls_reuse_and_replace_what_they_cache(rt, oracle):
+    """rt_render_region keeps the uploaded world and its buffers per GPU between calls.  The same scene again is
+    served from them; a scene that differs in one byte is not; sizes may grow and shrink; rt_release_cache drops all."""
+    cs, cam, sph, mat = scene(rt, "dev", 64, 4)
+    w, h = cs.image_width, cs.image_height
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=3)
+    for _ in range(3):
+        image, linear, _ = gpu_render(rt, cs, cam, sph, mat, seed=3)
+        assert np.array_equal(image, ref["image"]) and np.array_equal(linear, ref["linear"])
+    sph2 = sph.copy()
+    sph2["radius"][1] = 0.3                                   # same counts, one field changed
+    ref2 = oracle.render_region(w, h, (0, 0, w, h), cam, sph2, mat, precision=0, seed=3)
+    assert not np.array_equal(ref2["image"], ref["image"])
+    image, _, _ = gpu_render(rt, cs, cam, sph2, mat, seed=3)
+    assert np.array_equal(image, ref2["image"])
+    mat2 = mat.copy()
+    mat2["albedo"][1] = (0.9, 0.1, 0.1)
+    ref3 = oracle.render_region(w, h, (0, 0, w, h), cam, sph2, mat2, precision=0, seed=3)
+    image, _, _ = gpu_render(rt, cs, cam, sph2, mat2, seed=3)
+    assert np.array_equal(image, ref3["image"])
+    # a larger image, then the small one again, in another precision (the accumulator's element size changes)
+    csb, camb, _, _ = scene(rt, "dev", 200, 2)
+    big, _, _ = gpu_render(rt, csb, camb, sph, mat, seed=3, precision=rt.PRECISION_MIXED)
+    refb = oracle.render_region(csb.image_width, csb.image_height, (0, 0, csb.image_width, csb.image_height), camb, sph, mat, precision=1, seed=3, threads=4)
+    assert np.array_equal(big, refb["image"])
+    image, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=3)
+    assert np.array_equal(image, ref["image"])
+    assert rt.render_ppm(w, h, cam, sph, mat, seed=3) == rt.serialize_ppm(ref["image"])
+    rt.release_cache()
+    image = np.zeros((h, w, 3))
+    rt.render_region(image, (0, 0, w, h), cam, sph, mat, seed=3)   # without linear_out this time
+    assert np.array_equal(image, ref["image"])

@@ -51,6 +51,24 @@ def test_rng_streams_are_distinct_and_uniform(oracle):
     assert chi2 < 50.0  # 15 degrees of freedom: P(chi2 > 50) ~ 1e-5
 
 
+@pytest.mark.parametrize("mtype", [4, 5])
+def test_f32_metal_kinds_against_python_statement(rt, oracle, mtype):
+    """types 4 and 5 in the f32 throughput arithmetic: oracle against tests/pyref32.py"""
+    cs, sph, mat = rt.build_dev_scene(16)
+    cs.samples_per_pixel = 2
+    mat = mat.copy()
+    mat["type"][4] = mtype
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    region = (6, 2, 16, 9)
+    spl, ml = as_lists(sph, mat)
+    img, sums, seg = pyref32.render_region(w, h, region, cam_dict(cam), spl, ml, 17)
+    r = oracle.render_region(w, h, region, cam, sph, mat, precision=0, seed=17)
+    for (u, v), c in img.items():
+        assert tuple(r["image"][v, u]) == c
+    assert int(r["stats"][0]) == seg
+
+
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_intersection_closed_form(rt, oracle, precision):
     cases = json.load(open(os.path.join(GOLDEN, "intersection_kat.json")))
@@ -99,7 +117,7 @@ def test_scatter_against_pyref(oracle, name, material, ray_d, normal, front):
         assert ok == pok, name
         assert tuple(o_) == po and tuple(d_) == pd and tuple(att) == patt, name
         absorbed += not ok
-    if material[0] not in (1, 3):
+    if material[0] not in (1, 3, 4, 5):
         assert absorbed == 0  # only metal can absorb (main.odin:351)
 
 
@@ -119,13 +137,39 @@ def test_metal_fresnel_attenuation_closed_form(oracle):
         assert np.allclose(att, albedo, rtol=0, atol=tol)
 
 
-def test_metal_fresnel_render_against_pyref(rt, oracle):
-    """the three-material scene with its gold switched to the Fresnel variant: f64 oracle = pure-Python restatement"""
+def test_metal_schlick_and_hoffman_closed_form(oracle):
+    """METAL_FRESNEL_KIND 0 and 1 (main.odin:333-339) as material types 4 and 5.  Normal incidence: both give
+    r0 = ((1 - 1/n)/(1 + 1/n))^2 (the Hoffman correction carries a factor (1 - cos)^6 = 0).  At cos = 1/7 the
+    Lazanyi/Hoffman term peaks: Schlick minus a*cos*(1-cos)^6 with a = 7^7/6^6 (r0 - 0.5) + 49/6 (1 - r0), which
+    for h = 0.5 makes the reflectance there exactly h -- that is the construction of Hoffman's paper, and it only
+    comes out with real quotients (the reference's integer 17 and 8 give another number)."""
+    albedo = (0.8, 0.6, 0.2)
+    rel = 100000.0 / 127035.0
+    r0 = ((1.0 - rel) / (1.0 + rel)) ** 2
+    lerp = lambda t: [a * (1 - t) + t for a in albedo]
+    for precision, tol in ((1, 1e-15), (0, 2e-6), (2, 2e-6)):
+        for mtype in (4, 5):
+            _, _, att, ok = oracle.material_scatter(precision, (mtype, albedo, 0.0), (0, 2, 0), (0.0, -1.0, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+            assert ok and np.allclose(att, lerp(r0), rtol=0, atol=tol), (precision, mtype)
+        c = 1.0 / 7.0
+        d = (math.sqrt(1.0 - c * c), -c, 0.0)   # unit direction whose cosine with the normal (0, 1, 0) is 1/7
+        schlick = r0 + (1.0 - r0) * (1.0 - c) ** 5
+        _, _, att, _ = oracle.material_scatter(precision, (4, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert np.allclose(att, lerp(schlick), rtol=0, atol=tol)
+        _, _, att, _ = oracle.material_scatter(precision, (5, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert np.allclose(att, lerp(0.5), rtol=0, atol=max(tol, 1e-12))
+        a_int = 17 * (r0 - 0.5) + 8 * (1.0 - r0)   # what the reference's integer quotients would give: not 0.5
+        assert abs((schlick - a_int * c * (1.0 - c) ** 6) - 0.5) > 1e-3
+
+
+@pytest.mark.parametrize("mtype", [3, 4, 5])
+def test_metal_fresnel_render_against_pyref(rt, oracle, mtype):
+    """the three-material scene with its gold switched to a Fresnel variant: f64 oracle = pure-Python restatement"""
     cs, sph, mat = rt.build_dev_scene(20)
     cs.samples_per_pixel = 3
     mat = mat.copy()
     assert int(mat["type"][4]) == 1
-    mat["type"][4] = 3
+    mat["type"][4] = mtype
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
     spl, ml = as_lists(sph, mat)

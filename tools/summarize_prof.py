@@ -9,6 +9,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel-trace --stats:", os.path.relpath(f, out), "(bench.py --steps 3 --warmup 1, 500 spp)")
     for row in csv.DictReader(open(f)):
@@ -48,11 +49,15 @@ if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
             pk, rest = g("SQ_INSTS_VALU_FMA_F32"), g("SQ_INSTS_VALU") - g("SQ_INSTS_VALU_FMA_F32")
             print(f"   VALU issue cycles      = (4 * FMA_F32 + 2 * other VALU) / 1024 SIMDs / kernel cycles = {(4 * pk + 2 * rest) / 1024 / cyc:.3f}")
             print(f"   instruction mix        : FMA_F32 {pk / g('SQ_INSTS_VALU'):.3f} of VALU instructions; SALU per VALU {g('SQ_INSTS_SALU', 0) / g('SQ_INSTS_VALU'):.3f}")
+            f64 = sum(g(k, 0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"))
+            if f64:
+                print(f"   f64 instructions       : {f64 / g('SQ_INSTS_VALU'):.3f} of VALU instructions (FMA {g('SQ_INSTS_VALU_FMA_F64', 0):.4g}, ADD {g('SQ_INSTS_VALU_ADD_F64', 0):.4g}, MUL {g('SQ_INSTS_VALU_MUL_F64', 0):.4g}, TRANS {g('SQ_INSTS_VALU_TRANS_F64', 0):.4g})")
     if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY") is not None:
         print(f"   wave time              : issue-stalled {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}, parked on waitcnt {g('SQ_WAIT_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}, executing {g('SQ_ACTIVE_INST_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}")
 if traffic:
     f, w = traffic.get("traffic_fetch", float("nan")), traffic.get("traffic_write", float("nan"))
     print("== memory-side traffic of one 500-spp dispatch (4.05e8 samples; rocprofv3 reports KiB; FETCH_SIZE doubled as gfx950 tallies 128-B reads at 64 B)")
-    print(f"   FETCH_SIZE {f:.6g} KiB -> {2 * f * 1024 / 1e9:.4f} GB read;  WRITE_SIZE {w:.6g} KiB -> {w * 1024 / 1e9:.3f} GB written (8-byte integer atomics, width uncalibrated)")
+    what = "8-byte integer atomics, width uncalibrated" if mode == "f32" else "24-byte stores of the staged sample colours"
+    print(f"   FETCH_SIZE {f:.6g} KiB -> {2 * f * 1024 / 1e9:.4f} GB read;  WRITE_SIZE {w:.6g} KiB -> {w * 1024 / 1e9:.3f} GB written ({what})")
     allc["TRAFFIC_BYTES_500SPP"] = (2 * f + w) * 1024
 json.dump(allc, open(os.path.join(out, "counters.json"), "w"), indent=1)
