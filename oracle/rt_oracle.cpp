@@ -280,11 +280,18 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
  * share sits in its constant Km = K - 2^-17 (|center|^2 + r^2) (rounded down), the ray's share in
  * aoo = a|o|^2 (1 - 2^-17).  A sphere is kept unless the lowered discriminant is negative; of the
  * kept ones those with h < -behind and a*c > 0 (certainly behind an origin certainly outside) are
- * dropped as well, behind = 2^-20 |d| (reach + |o|) >= 8 u |d| S bounding the error of h.  The bound
+ * dropped as well, behind = 2^-20 |d|_1 (reach + |o|_1) >= 2 * 8 u |d| S bounding twice the error of h
+ * (|.|_1 the sum of absolute components, an upper bound of the length that needs no square root).
+ * The sphere a scattered segment starts on is dropped under the same condition on h when its c
+ * (main.odin:248) is known to be tiny: the origin p = o' + t d' was a root of that sphere's
+ * equation, so |c| <= 64 * 2^-53 (reach + |o'|)^2 =: B (o' the previous origin; 21 units from the
+ * root and the hit point, 4 from evaluating c), and with |h| >= behind/2 the roots of
+ * main.odin:253-257 are <= 0 (c >= 0) or the far one is c/(h - sqrt(disc)) <= B/behind, which is
+ * below t_min when B < 9e-4 behind.  The bound
  * needs normal f32 numbers throughout: spheres with 2^-20 <= |r| and |center| + |r| <= 2^20 (else
  * the filter is not used at all), rays with 2^-40 <= a <= 2^40 and |o|^2 <= 2^40 (else the ray keeps
  * every sphere). */
-struct filter_ray { expanded_ray e; float behind; bool in_range; };
+struct filter_ray { expanded_ray e; float behind, reach_o; bool in_range; };
 inline float sphere_constant_lowered(float cx, float cy, float cz, float radius) {
     const double c2 = static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz, r2 = static_cast<double>(radius) * radius;
     const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 131072.0);
@@ -299,18 +306,21 @@ inline filter_ray make_filter_ray(const ray_t<double> &r, float reach) {
     f.e = expand_ray(rf);
     const float o_o = dot(rf.origin, rf.origin);
     f.e.aoo = f.e.aoo * (1.0f - 7.62939453125e-06f);
-    f.behind = 9.5367431640625e-07f * std::sqrt(f.e.a) * (reach + std::sqrt(o_o));
+    f.reach_o = reach + (std::fabs(rf.origin.x) + std::fabs(rf.origin.y) + std::fabs(rf.origin.z));
+    f.behind = 9.5367431640625e-07f * (std::fabs(rf.direction.x) + std::fabs(rf.direction.y) + std::fabs(rf.direction.z)) * f.reach_o;
     f.in_range = (f.e.a >= 9.094947017729282e-13f) && (f.e.a <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f);
+    if (!f.in_range) f.reach_o = FLT_MAX;
     return f;
 }
-inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Km) {
+/* on_start: the sphere is the one the segment starts on and its c is known to be below 9e-4 behind */
+inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Km, bool on_start = false) {
     if (!f.in_range) return true;
     const expanded_ray &e = f.e;
     const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
     const float m = std::fmaf(Km, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
     const float disc = std::fmaf(h, h, -m);
     if (disc < 0) return false;
-    if (h < -f.behind && m > 0) return false;
+    if (h < -f.behind && (m > 0 || on_start)) return false;
     return true;
 }
 
@@ -497,7 +507,8 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
     ray_t<Real> ray{ray_origin, pixel_sample_position - ray_origin};
     vec3<Real> sample_color{Real(1), Real(1), Real(1)};
     const int64_t n = static_cast<int64_t>(sc.spheres.size());
-    int64_t start_sphere = -1; /* throughput arithmetic: the sphere this segment's origin lies on (none for a camera ray) */
+    int64_t start_sphere = -1; /* throughput and mixed arithmetic: the sphere this segment's origin lies on (none for a camera ray) */
+    float start_cc_bound = 0.0f, next_cc_bound = 0.0f; /* mixed mode: bound on |c| of main.odin:248 for that sphere */
     for (int64_t bounce = 0; bounce <= sc.max_ray_bounces; ++bounce) { /* 0..=max  main.odin:535 */
         ++*segments;
         Real closest_t = std::numeric_limits<Real>::max();
@@ -516,8 +527,10 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             }
         } else if constexpr (MIXED) {
             const filter_ray f = make_filter_ray(ray, sc.filter_reach);
+            const bool skip_start = start_sphere >= 0 && f.in_range && start_cc_bound < 9.0e-4f * f.behind;
+            next_cc_bound = 7.2e-15f * f.reach_o * f.reach_o; /* 64 * 2^-53 (reach + |o|)^2, for the segment that follows */
             for (int64_t i = 0; i < n; ++i) {
-                const bool keep = !sc.filter_ok || mixed_filter(f, sc.spheres[i].center32, sc.spheres[i].Km);
+                const bool keep = !sc.filter_ok || mixed_filter(f, sc.spheres[i].center32, sc.spheres[i].Km, skip_start && i == start_sphere);
                 Real t = ray_sphere_intersection<Real>(ray, sc.spheres[i].center, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
                 if (!keep) { if (t < closest_t) ++fc->wrongly_dropped; continue; } /* evaluated only to audit the filter */
                 ++fc->kept;
@@ -542,6 +555,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             scatter_result<Real> s = material_scatter<Real, FMA>(mat, ray, hit, sg);
             if (s.ok) {
                 start_sphere = hit_index;
+                start_cc_bound = next_cc_bound;
                 ray = s.ray_out;
                 sample_color = sample_color * s.attenuation;
             } else {
@@ -697,8 +711,9 @@ int32_t oracle_render_region(int32_t precision, double *image, double *linear, d
 }
 
 /* The mixed mode's filter for one ray and one sphere, with its intermediate values:
- * out = {lowered discriminant, lowered a*c, h, behind, in_range (0/1), kept (0/1)} */
-void oracle_mixed_filter(const double *o, const double *d, const double *c, double radius, double reach, double *out) {
+ * out = {lowered discriminant, lowered a*c, h, behind, in_range (0/1), kept (0/1), bound on |c| for the next segment}.
+ * start_cc_bound >= 0: the sphere is the one the segment starts on, with that bound on its |c| (main.odin:248). */
+void oracle_mixed_filter(const double *o, const double *d, const double *c, double radius, double reach, double start_cc_bound, double *out) {
     ray_t<double> r{{o[0], o[1], o[2]}, {d[0], d[1], d[2]}};
     const filter_ray f = make_filter_ray(r, static_cast<float>(reach));
     const vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
@@ -707,7 +722,9 @@ void oracle_mixed_filter(const double *o, const double *d, const double *c, doub
     const float h = std::fmaf(cf.z, e.dz, std::fmaf(cf.y, e.dy, std::fmaf(cf.x, e.dx, -e.d_o)));
     const float m = std::fmaf(Km, e.a, std::fmaf(cf.z, e.aoz, std::fmaf(cf.y, e.aoy, std::fmaf(cf.x, e.aox, e.aoo))));
     out[0] = std::fmaf(h, h, -m); out[1] = m; out[2] = h; out[3] = f.behind; out[4] = f.in_range ? 1.0 : 0.0;
-    out[5] = mixed_filter(f, cf, Km) ? 1.0 : 0.0;
+    const bool on_start = start_cc_bound >= 0.0 && f.in_range && static_cast<float>(start_cc_bound) < 9.0e-4f * f.behind;
+    out[5] = mixed_filter(f, cf, Km, on_start) ? 1.0 : 0.0;
+    out[6] = 7.2e-15f * f.reach_o * f.reach_o;
 }
 
 /* ray_sphere_intersection with explicit inputs (o, d, c are 3 doubles each) */

@@ -166,7 +166,9 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU_ATTR
+// The mixed kernel needs 98 registers as compiled freely, two more than five waves per SIMD allow; asked for five it
+// fits (measured 1.6 % faster).  The other instantiations keep the compiler's choice (1..8 is no constraint).
+#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? 5 : 1, MIXED ? 5 : 8)))
 #else
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
@@ -265,10 +267,23 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // throughput arithmetic: the sphere the current segment starts on (-1 for a camera ray) and its centre
     int start_sphere = -1;
     V3<Real> start_center = {Real(0), Real(0), Real(0)};
+    // mixed mode: bound on |c| of main.odin:248 for the sphere this segment starts on (see the scan), and the
+    // reach + |o| of the segment being traced, from which the next segment's bound is formed
+    float start_cc_bound = 0.0f, reach_o = 0.0f;
+    bool skip_start = false;
     uint32_t segments = 0, started = 0;
     uint32_t bvh_nodes = 0, bvh_tests = 0; // hierarchy mode: boxes and spheres this lane tested
 #ifdef RT_DIAG_BVH
     uint32_t bvh_wave_steps = 0; // diagnostic build: trips of the traversal loop counted by the lowest active lane
+#endif
+#ifdef RT_DIAG_PHASES
+    // diagnostic build: wave cycles (s_memtime) per phase of the segment loop, summed over waves into stats[5..7] and
+    // [1..2]: 5 = dealing + camera ray, 6 = closest-hit scan without its slow path, 7 = slow path (park + resolve),
+    // 1 = shading of a hit, 2 = background + end of sample
+    unsigned long long ph_fresh = 0, ph_scan = 0, ph_slow = 0, ph_hit = 0, ph_end = 0, ph_t = 0, ph_in = 0;
+#define RT_PHASE(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define RT_PHASE(acc) ((void)0)
 #endif
 #ifdef RT_DIAG_COUNTERS
     // diagnostic build: how often the scan leaves its straight-line code
@@ -278,6 +293,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 #define RT_DIAG_COUNT(x) ((void)0)
 #endif
 
+#ifdef RT_DIAG_PHASES
+    ph_t = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         if constexpr (QUEUE) {
             // Deal (pixel, sample) pairs to the lanes that need one, in lane order, taking new
@@ -355,6 +373,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             fresh = false;
         }
 
+        RT_PHASE(ph_fresh);
         // ---------------- closest-hit scan (main.odin:536-546 with :240-263 inlined)
         const Real a = dot(rd, rd);
         const Real inv_a = FMA ? Real(1) / a : Real(0); // throughput arithmetic: roots are (h -+ sqrt(disc)) * (1/a)
@@ -425,6 +444,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         };
         // the uncommon continuation for one sphere: some lane's line meets it
         float behind = 0.0f; // mixed mode: h below -behind is certainly negative (set with the filter's per-ray values)
+        skip_start = false;
         auto park = [&](const auto h, const auto cc, const auto disc, const int i) {
             using T = decltype(disc);
             // mixed mode: the filter's discriminant carries its error margin (see below), and a NaN keeps the sphere
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
                 // (the sphere the segment starts on was tested before the scan)
                 // Mixed mode: only when both signs are certain despite the f32 rounding.
-                const bool ahead = MIXED ? !((h < T(-behind)) && (cc > T(0))) : ((h > T(0)) || (cc < T(0)));
+                const bool ahead = MIXED ? !((h < T(-behind)) && ((cc > T(0)) || (skip_start && i == start_sphere))) : ((h > T(0)) || (cc < T(0)));
                 const bool cand = meets && ahead && (!FMA || i != start_sphere);
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
@@ -504,14 +524,25 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             float aox = fa * (-2.0f * fo.x), aoy = fa * (-2.0f * fo.y), aoz = fa * (-2.0f * fo.z), aoo = fa * o_o;
             if constexpr (MIXED) {
                 aoo = aoo * (1.0f - 7.62939453125e-06f); // the ray's share of the margin: 2^-17 a |o|^2
-                // h < -behind is certainly negative: h is off by at most 8 u |d| S, and S <= reach + |o|
-                behind = 9.5367431640625e-07f * sqrt_rn(fa) * (P.filter_reach + sqrt_rn(o_o)); // 2^-20 = 16 u
+                // h < -behind is certainly negative: h is off by at most 8 u |d| S, S <= reach + |o|, and the sums of
+                // absolute components bound the lengths from above
+                reach_o = P.filter_reach + (abs_rn(fo.x) + abs_rn(fo.y) + abs_rn(fo.z));
+                behind = 9.5367431640625e-07f * (abs_rn(fd.x) + abs_rn(fd.y) + abs_rn(fd.z)) * reach_o; // 2^-20 = 16 u
+                // The sphere this segment starts on.  Its origin p = o' + t d' was a root of that sphere's equation,
+                // so c = |centre - p|^2 - r^2 (main.odin:248) is zero up to rounding: |c| <= 64 * 2^-53 (reach + |o'|)^2
+                // (21 from the root and the hit point, 4 from evaluating c; o' the previous origin).  With h
+                // certainly below -behind/2 the roots of main.odin:253-257 are <= 0 (c >= 0) or the far one is
+                // c/(h - sqrt(disc)) <= |c| / (2|h|) <= |c| / behind; below t_min the sphere cannot be hit and
+                // ray_sphere_intersection need not be evaluated for it.
+                skip_start = start_sphere >= 0 && start_cc_bound < 9.0e-4f * behind;
                 const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f); // 2^-40, 2^40
                 if (!in_range) {
                     // every sphere is a candidate of this ray: h = 0, a*c = -1, discriminant 1
                     fd = {0.0f, 0.0f, 0.0f}; d_o = 0.0f; fa = 0.0f;
                     aox = 0.0f; aoy = 0.0f; aoz = 0.0f; aoo = -1.0f;
                     behind = Lim<float>::max_v;
+                    skip_start = false;
+                    reach_o = Lim<float>::max_v;
                 }
             }
             if constexpr (BVH != 0) {
@@ -635,7 +666,13 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= 0.0f) != 0ull, 0)) {
 #endif
                     RT_DIAG_COUNT(diag_entries);
+#ifdef RT_DIAG_PHASES
+                    ph_in = __builtin_amdgcn_s_memtime();
+#endif
                     park(hp.x, mp.x, dp.x, i); park(hp.y, mp.y, dp.y, i + 1); park(hq.x, mq.x, dq.x, i + 2); park(hq.y, mq.y, dq.y, i + 3);
+#ifdef RT_DIAG_PHASES
+                    ph_slow += __builtin_amdgcn_s_memtime() - ph_in;
+#endif
                 }
             };
             // two register sets, A and B, each holding one group: while one is tested the other loads
@@ -672,8 +709,15 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 test_group(b0, b1, b2, b3, i + 4);
             }
         }
+#ifdef RT_DIAG_PHASES
+        ph_in = __builtin_amdgcn_s_memtime();
+#endif
         if (pend >= 0) resolve();
+#ifdef RT_DIAG_PHASES
+        ph_slow += __builtin_amdgcn_s_memtime() - ph_in;
+#endif
         ++segments;
+        RT_PHASE(ph_scan);
 
         // ---------------- shading
         bool ended;
@@ -773,6 +817,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             if (ok) {
                 ro = p; rd = dir;
                 start_sphere = hit; start_center = center;
+                if constexpr (MIXED) start_cc_bound = 7.2e-15f * reach_o * reach_o; // 64 * 2^-53 = 7.1e-15, rounded up
                 color = color * atten;
                 ++bounce;
                 ended = bounce > P.max_bounces; // `for _ in 0..=max_ray_bounces` ran out: colour is kept (main.odin:535)
@@ -780,6 +825,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 color = {Real(0), Real(0), Real(0)};
                 ended = true;
             }
+            RT_PHASE(ph_hit);
         } else {
             // background (main.odin:570-572, :412-418): lerp(a, b, t) = a*(1-t) + b*t
             const V3<Real> d = normalize<Real, FMA>(rd);
@@ -806,6 +852,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             }
             fresh = true;
         }
+        RT_PHASE(ph_end);
     }
 
     if constexpr (!QUEUE) {
@@ -843,6 +890,15 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             if (lane == 0) atomicAdd(&P.stats[7], static_cast<unsigned long long>(ws));
 #endif
         }
+#ifdef RT_DIAG_PHASES
+        if (lane == 0) {
+            atomicAdd(&P.stats[5], ph_fresh);
+            atomicAdd(&P.stats[6], ph_scan - ph_slow);
+            atomicAdd(&P.stats[7], ph_slow);
+            atomicAdd(&P.stats[1], ph_hit);
+            atomicAdd(&P.stats[2], ph_end);
+        }
+#endif
 #ifdef RT_DIAG_COUNTERS
         // entries: per wave (uniform, lane 0 holds it); resolves: executions by the wave (counted by one lane each); parked: lane total
         uint32_t par = diag_parked, res = diag_resolves;

@@ -30,7 +30,7 @@ class Oracle:
         L.oracle_quantize_rgb8.argtypes = [vp, i64, vp]
         L.oracle_serialize_ppm.argtypes = [vp, i64, i64, vp]
         L.oracle_serialize_ppm.restype = i64
-        L.oracle_mixed_filter.argtypes = [vp, vp, vp, dbl, dbl, vp]
+        L.oracle_mixed_filter.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp]
         L.oracle_mixed_filter.restype = None
         self.L = L
 
@@ -58,13 +58,14 @@ class Oracle:
         o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))
         return float(self.L.oracle_ray_sphere_intersection(precision, o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, t_min, t_max))
 
-    def mixed_filter(self, o, d, c, radius, reach):
+    def mixed_filter(self, o, d, c, radius, reach, start_cc_bound=-1.0):
         """the f32 candidate filter of RT_PRECISION_MIXED for one ray and one sphere ->
-        dict(disc, m, h, behind, in_range, kept)"""
+        dict(disc, m, h, behind, in_range, kept, next_cc_bound); start_cc_bound >= 0: the segment starts on this
+        sphere and |c| of main.odin:248 is known to be at most that"""
         o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))
-        out = np.zeros(6, dtype=np.float64)
-        self.L.oracle_mixed_filter(o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, reach, out.ctypes.data)
-        return dict(disc=out[0], m=out[1], h=out[2], behind=out[3], in_range=bool(out[4]), kept=bool(out[5]))
+        out = np.zeros(7, dtype=np.float64)
+        self.L.oracle_mixed_filter(o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, reach, start_cc_bound, out.ctypes.data)
+        return dict(disc=out[0], m=out[1], h=out[2], behind=out[3], in_range=bool(out[4]), kept=bool(out[5]), next_cc_bound=out[6])
 
     def material_scatter(self, precision, material, ray_o, ray_d, hit_p, hit_n, front_face, seed, pixel, sample, bounce):
         m = np.zeros(1, dtype=rt.MATERIAL_DTYPE)

@@ -85,6 +85,47 @@ def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
     assert worst_low > 0
 
 
+def test_start_sphere_rule_only_drops_what_the_reference_misses(oracle):
+    """A segment that starts on a sphere (its origin is the hit point the reference computed on it) and leaves it:
+    the filter may drop that sphere only if main.odin:240-263 evaluated in f64 reports no hit.  Hit points come from
+    the reference's own root formula, from near and far previous origins; outgoing directions include grazing ones
+    (almost tangent, where the far root of the start sphere creeps up towards t_min) and very short ones."""
+    rng = np.random.default_rng(77)
+    dropped = kept = hits_kept = 0
+    for _ in range(8000):
+        scale = 10.0 ** rng.uniform(-2, 3)
+        c = rng.normal(size=3) * scale * rng.choice([0.0, 1.0, 30.0])
+        r = scale * 10.0 ** rng.uniform(-2, 0.5)
+        # previous segment: from o0 towards a point inside the sphere
+        o0 = c + rng.normal(size=3) * r * 10.0 ** rng.uniform(0.2, 4)
+        d0 = (c + rng.normal(size=3) * r * 0.55) - o0
+        d0 *= 10.0 ** rng.uniform(-2, 2) / np.linalg.norm(d0)
+        t = oracle.ray_sphere_intersection(1, o0, d0, c, r, 0.001, 1.7976931348623157e308)
+        if not (t < 1e300):
+            continue
+        p = o0 + t * d0                                   # hit.p = ray.origin + closest_t * ray.direction (main.odin:553)
+        n = (p - c) / r
+        reach = float(np.linalg.norm(np.float32(c).astype(np.float64)) + abs(np.float32(r))) * 1.000001
+        prev = oracle.mixed_filter(o0, d0, c, r, reach)
+        # outgoing direction: mostly away from the sphere, often almost tangent
+        tang = rng.normal(size=3)
+        tang -= n * (tang @ n)
+        tang /= np.linalg.norm(tang)
+        out = tang + n * rng.choice([1.0, 1e-2, 1e-5, 1e-8, 1e-11, -1e-9, 0.0]) * rng.uniform(0.1, 1.0)
+        out *= 10.0 ** rng.uniform(-6, 2) / np.linalg.norm(out)
+        f = oracle.mixed_filter(p, out, c, r, reach, start_cc_bound=prev["next_cc_bound"])
+        t2 = oracle.ray_sphere_intersection(1, p, out, c, r, 0.001, 1.7976931348623157e308)
+        hit = t2 < 1e300
+        if f["kept"]:
+            kept += 1
+            hits_kept += hit
+        else:
+            dropped += 1
+            assert not hit, (c, r, o0, d0, out, t2)
+    print(f"start-sphere rule: dropped {dropped}, kept {kept} (of which the reference reports a hit for {hits_kept})")
+    assert dropped > 500 and hits_kept > 0
+
+
 def test_out_of_range_rays_keep_every_sphere(oracle):
     c, r = (0.0, 0.0, -1.0), 0.5
     for o, d in (((0.0, 0.0, 0.0), (0.0, 0.0, -1e-25)), ((0.0, 0.0, 0.0), (0.0, 3e21, 0.0)), ((2e7, 0.0, 0.0), (0.0, 1.0, 0.0)),

@@ -28,3 +28,8 @@ s = st.cpu().numpy()
 seg, iters = int(s[0]), int(s[4])
 print(f"{os.path.basename(os.environ.get('RT_MI355X_LIB', 'default'))} {mode}: kernel {best / 1e6:.2f} ms, segments/sample {seg / (w * h * spp):.3f}, lane occupancy {seg / max(1, 64 * iters):.3f}, "
       f"SIMD cycles per wave iteration {best * 2.4 * 1024 / max(1, iters):.0f}; counters 5..7 per iteration: {s[5] / max(1, iters):.2f} {s[6] / max(1, iters):.2f} {s[7] / max(1, iters):.2f}")
+if os.environ.get("RT_MI355X_LIB", "").endswith("phases.so"):
+    # RT_DIAG_PHASES build: wave cycles (s_memtime ticks, 100 MHz) per phase, summed over waves
+    ph = {"deal + camera ray": s[5], "scan (fast path)": s[6], "scan slow path (park + resolve)": s[7], "shading of hits": s[1], "background + end of sample": s[2]}
+    tot = float(sum(ph.values()))
+    print("   wave time by phase: " + ", ".join(f"{k} {v / tot:.3f}" for k, v in ph.items()))
