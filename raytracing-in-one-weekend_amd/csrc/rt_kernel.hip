@@ -107,8 +107,30 @@ struct Draws {
     }
 };
 
+// The rejection loops of main.odin:196-202 and :216-222 in f64, without f64 arithmetic on rejected candidates.
+// A draw is u = k * 2^-24 with a 24-bit integer k, and float64_range(-1, 1 + F64_EPSILON) maps it to
+// (hi - lo) * u + lo = 2u - 1 exactly (hi - lo = 2 + 2^-52 rounds to 2; the pull-back of a value >= hi never
+// applies), so a candidate coordinate is X * 2^-23 with the integer X = k - 2^23.  Its square has at most 48
+// significant bits and the sum of two or three squares at most 50: dot(p, p) (main.odin:28-30) is exact in f64 and
+// equals (X^2 + Y^2 + Z^2) * 2^-46.  The loop therefore tests the integers -- converted to f64, where products and
+// sums below 2^53 are exact as well -- and only the accepted candidate is scaled: the same values, bit for bit.
+__device__ __forceinline__ double centred_draw(Draws &g) { return static_cast<double>(static_cast<int32_t>(g.next_u32() >> 8) - 8388608); }
+__device__ __forceinline__ V3<double> random_unit_vector_f64(Draws &g) {
+    double X = 0.0, Y = 0.0, Z = 0.0, sq = 0.0;
+    for (int it = 0; it < REJECTION_CAP; ++it) {
+        X = centred_draw(g); Y = centred_draw(g); Z = centred_draw(g);
+        sq = __builtin_fma(Z, Z, __builtin_fma(Y, Y, X * X)); // exact
+        if (0.0 < sq && sq <= 70368744177664.0) break;         // 0 < |p|^2 <= 1 with |p|^2 = sq * 2^-46
+    }
+    const double scale = 1.0 / 8388608.0;
+    const V3<double> p = {X * scale, Y * scale, Z * scale};
+    const double len = sqrt_rn(sq * (1.0 / 70368744177664.0));
+    return {p.x / len, p.y / len, p.z / len};
+}
+
 // random_unit_vector (main.odin:194-203)
 template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> random_unit_vector(Draws &g) {
+    if constexpr (std::is_same<Real, double>::value) return random_unit_vector_f64(g);
     const Real hi = Real(1) + Real(2.220446049250313e-16); // 1 + F64_EPSILON, rounds to 1 in f32
     V3<Real> p = {Real(0), Real(0), Real(0)};
     Real lsq = Real(0);
@@ -359,6 +381,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // random_point_on_disk (main.odin:214-223)
                 const Real hi = Real(1) + Real(2.220446049250313e-16);
                 Real px = Real(0), py = Real(0);
+                if constexpr (std::is_same<Real, double>::value) {
+                    // the integer form of the loop (see random_unit_vector_f64): |p|^2 = (X^2 + Y^2) * 2^-46, exact
+                    for (int it = 0; it < REJECTION_CAP; ++it) {
+                        px = centred_draw(g); py = centred_draw(g);
+                        if (__builtin_fma(py, py, px * px) <= 70368744177664.0) break;
+                    }
+                    px = px * (1.0 / 8388608.0); py = py * (1.0 / 8388608.0);
+                } else
                 for (int it = 0; it < REJECTION_CAP; ++it) {
                     px = g.range<Real>(Real(-1), hi);
                     py = g.range<Real>(Real(-1), hi);
