@@ -99,12 +99,14 @@ struct Draws {
     __device__ __forceinline__ uint32_t next_u32() { c += 0xc2b2ae35u; return mix32(kb + c) ^ wp; }
     // rand.float64(): uniform [0,1) with 24 random bits, exact in f32 and f64
     template <typename Real> __device__ __forceinline__ Real next() { return static_cast<Real>(next_u32() >> 8) * static_cast<Real>(1.0 / 16777216.0); }
-    // rand.float64_range(lo, hi): (hi-lo)*u + lo, a result that reaches hi is pulled back below it
-    template <typename Real> __device__ __forceinline__ Real range(Real lo, Real hi) {
-        Real val = (hi - lo) * next<Real>() + lo;
-        if (val >= hi) val = max_std(lo, hi * (Real(1) - Lim<Real>::eps));
-        return val;
-    }
+    // rand.float64_range(lo, hi) is (hi-lo)*u + lo, and a result that reaches hi is pulled back below it.  For the
+    // two ranges the path uses and u = k * 2^-24 this is exact arithmetic on small integers in f32 and in f64:
+    //   (-1, 1 + F64_EPSILON):  hi - lo rounds to 2 (in f32 hi itself rounds to 1), 2u - 1 = (k - 2^23) * 2^-23;
+    //   (-0.5, 0.5)          :  hi - lo = 1,                                        u - 0.5 = (k - 2^23) * 2^-24;
+    // both representable, both below hi, so the pull-back never applies and one fused operation on the integer
+    // returns the very same number.
+    template <typename Real> __device__ __forceinline__ Real range_pm1() { return fma_rn(static_cast<Real>(next_u32() >> 8), static_cast<Real>(1.0 / 8388608.0), Real(-1)); }
+    template <typename Real> __device__ __forceinline__ Real range_pm_half() { return fma_rn(static_cast<Real>(next_u32() >> 8), static_cast<Real>(1.0 / 16777216.0), Real(-0.5)); }
 };
 
 // The rejection loops of main.odin:196-202 and :216-222 in f64, without f64 arithmetic on rejected candidates.
@@ -131,13 +133,12 @@ __device__ __forceinline__ V3<double> random_unit_vector_f64(Draws &g) {
 // random_unit_vector (main.odin:194-203)
 template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> random_unit_vector(Draws &g) {
     if constexpr (std::is_same<Real, double>::value) return random_unit_vector_f64(g);
-    const Real hi = Real(1) + Real(2.220446049250313e-16); // 1 + F64_EPSILON, rounds to 1 in f32
     V3<Real> p = {Real(0), Real(0), Real(0)};
     Real lsq = Real(0);
     for (int it = 0; it < REJECTION_CAP; ++it) {
-        p.x = g.range<Real>(Real(-1), hi);
-        p.y = g.range<Real>(Real(-1), hi);
-        p.z = g.range<Real>(Real(-1), hi);
+        p.x = g.range_pm1<Real>();
+        p.y = g.range_pm1<Real>();
+        p.z = g.range_pm1<Real>();
         lsq = dot(p, p);
         if (Real(0) < lsq && lsq <= Real(1)) break;
     }
@@ -373,13 +374,12 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             ++started;
             ks = mix32(kp + 0x9e3779b9u * (P.sample_begin + s + 1u));
             Draws g(ks, wp, 0u);
-            Real jx = g.range<Real>(Real(-0.5), Real(0.5));
-            Real jy = g.range<Real>(Real(-0.5), Real(0.5));
+            Real jx = g.range_pm_half<Real>();
+            Real jy = g.range_pm_half<Real>();
             V3<Real> psp = cam3(C, 3) + (static_cast<Real>(u) + jx) * cam3(C, 1) + (static_cast<Real>(v) + jy) * cam3(C, 2);
             ro = cam3(C, 0);
             if (C[18] > Real(0)) {
                 // random_point_on_disk (main.odin:214-223)
-                const Real hi = Real(1) + Real(2.220446049250313e-16);
                 Real px = Real(0), py = Real(0);
                 if constexpr (std::is_same<Real, double>::value) {
                     // the integer form of the loop (see random_unit_vector_f64): |p|^2 = (X^2 + Y^2) * 2^-46, exact
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     px = px * (1.0 / 8388608.0); py = py * (1.0 / 8388608.0);
                 } else
                 for (int it = 0; it < REJECTION_CAP; ++it) {
-                    px = g.range<Real>(Real(-1), hi);
-                    py = g.range<Real>(Real(-1), hi);
+                    px = g.range_pm1<Real>();
+                    py = g.range_pm1<Real>();
                     if (px * px + py * py <= Real(1)) break;
                 }
                 ro = ro + ((px * cam3(C, 4)) + (py * cam3(C, 5)));
