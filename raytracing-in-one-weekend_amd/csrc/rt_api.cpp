@@ -666,8 +666,10 @@ struct DeviceCache {
     void *text = nullptr; size_t text_bytes = 0;
     uint64_t *stats = nullptr;
     hipStream_t stream = nullptr;
+    void *pinned = nullptr; size_t pinned_bytes = 0; // page-locked host staging for the copy back
 };
 DeviceCache g_cache[MAX_DEVICES];
+constexpr size_t PINNED_STAGING_MAX = static_cast<size_t>(1) << 30; // larger results are copied straight into the caller's memory
 
 hipError_t ensure_bytes(void **buf, size_t *have, size_t need) {
     if (*buf != nullptr && *have >= need) return hipSuccess;
@@ -682,6 +684,7 @@ void release_cache_entry(DeviceCache &c) {
     rt_world_destroy(c.world); c.world = nullptr;
     c.scene.clear(); c.n_spheres = c.n_materials = -1;
     for (void **b : {&c.accum, &c.image, &c.linear, &c.text, reinterpret_cast<void **>(&c.stats)}) if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
     c.accum_bytes = c.image_bytes = c.linear_bytes = c.text_bytes = 0;
 }
 
@@ -730,6 +733,7 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
         int device = 0; bool cached = false;
         rt_world *world = nullptr; void *accum = nullptr; double *image = nullptr; double *linear = nullptr; char *text = nullptr;
         uint64_t *stats = nullptr; hipStream_t stream = nullptr;
+        void *pinned = nullptr; size_t pinned_bytes = 0; // host staging of the cached device (NULL: copy straight to the caller's memory)
     };
     std::vector<PerDevice> devs(count);
     const size_t n_px = static_cast<size_t>(width) * static_cast<size_t>(height);
@@ -788,6 +792,17 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
             if (e == hipSuccess && ppm_body) e = ensure_bytes(&c.text, &c.text_bytes, text_need);
             if (e == hipSuccess && o.linear_out && image_data) e = ensure_bytes(&c.linear, &c.linear_bytes, image_need);
             if (e == hipSuccess && c.stats == nullptr) e = hipMalloc(reinterpret_cast<void **>(&c.stats), sizeof(uint64_t) * RT_STATS_COUNT);
+            {
+                // staging for the rows of the region (whole image rows), twice with linear_out, plus the counters
+                const size_t rows = static_cast<size_t>(region.one_past_max_y - region.min_y);
+                const size_t stage_need = rows * static_cast<size_t>(width) * (ppm_body ? 12 : sizeof(rt_v3)) * ((o.linear_out && image_data) ? 2 : 1) + sizeof(uint64_t) * RT_STATS_COUNT;
+                if (e == hipSuccess && stage_need <= PINNED_STAGING_MAX && stage_need > c.pinned_bytes) {
+                    if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
+                    if (hipHostMalloc(&c.pinned, stage_need, hipHostMallocDefault) == hipSuccess) c.pinned_bytes = stage_need;
+                    else { c.pinned = nullptr; (void)hipGetLastError(); } // no page-locked memory: the direct copy still works
+                }
+                if (stage_need <= c.pinned_bytes) { d.pinned = c.pinned; d.pinned_bytes = c.pinned_bytes; }
+            }
             d.stream = c.stream; d.accum = c.accum; d.image = static_cast<double *>(c.image); d.text = static_cast<char *>(c.text);
             d.linear = (o.linear_out && image_data) ? static_cast<double *>(c.linear) : nullptr; d.stats = c.stats;
             if (e == hipSuccess && !same_scene(c)) {
@@ -823,39 +838,86 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
         else
             result = rt_finalize_ppm(d.world, d.accum, o.precision, width, height, strip_rows, g, count, cam->samples_per_pixel, d.text, d.stream);
     }
-    // copy each device's strips of the region back: rows [y0, y1), columns of the region
+    // Copy each device's strips of the region back: rows [y0, y1), columns of the region.  A device with a pinned
+    // staging buffer gets its rows (whole image rows, which are contiguous on the device) by asynchronous copies on
+    // its own stream, all devices at once, and the host then copies the region's columns out of the staging buffer;
+    // copying into the caller's pageable memory directly costs several times as much for small images.
     const size_t pitch = static_cast<size_t>(width) * sizeof(rt_v3);
     const size_t row_bytes = static_cast<size_t>(region.one_past_max_x - region.min_x) * sizeof(rt_v3);
-    for (int g = 0; g < count && result == RT_OK; ++g) {
+    auto for_each_span = [&](int g, auto &&fn) { // the row ranges device g owns, in image order
+        for (int64_t y0 = region.min_y + g * strip_rows; y0 < region.one_past_max_y; y0 += strip_rows * count) {
+            const int64_t y1 = std::min<int64_t>(region.one_past_max_y, count == 1 ? region.one_past_max_y : y0 + strip_rows);
+            if (!fn(y0, y1)) return false;
+            if (count == 1) break;
+        }
+        return true;
+    };
+    const size_t px_bytes = ppm_body ? 12 : sizeof(rt_v3);
+    for (int g = 0; g < count && result == RT_OK; ++g) { // enqueue
+        PerDevice &d = devs[g];
+        if (d.pinned == nullptr) continue;
+        hipError_t e = hipSetDevice(d.device);
+        size_t at = 0; // bytes staged so far
+        const char *src = ppm_body ? d.text : reinterpret_cast<const char *>(d.image);
+        for (int pass = 0; pass < ((o.linear_out && image_data) ? 2 : 1) && e == hipSuccess; ++pass) {
+            if (pass == 1) src = reinterpret_cast<const char *>(d.linear);
+            for_each_span(g, [&](int64_t y0, int64_t y1) {
+                const size_t bytes = static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * px_bytes;
+                e = hipMemcpyAsync(static_cast<char *>(d.pinned) + at, src + static_cast<size_t>(y0) * static_cast<size_t>(width) * px_bytes, bytes, hipMemcpyDeviceToHost, d.stream);
+                at += bytes;
+                return e == hipSuccess;
+            });
+        }
+        if (e == hipSuccess && o.stats) e = hipMemcpyAsync(static_cast<char *>(d.pinned) + d.pinned_bytes - sizeof(uint64_t) * RT_STATS_COUNT, d.stats, sizeof(uint64_t) * RT_STATS_COUNT, hipMemcpyDeviceToHost, d.stream);
+        if (e != hipSuccess) result = fail(RT_ERR_DEVICE, "collecting from device %d failed: %s", d.device, hipGetErrorString(e));
+    }
+    for (int g = 0; g < count && result == RT_OK; ++g) { // collect
         PerDevice &d = devs[g];
         hipError_t e = hipSetDevice(d.device);
         if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
-        for (int64_t y0 = region.min_y + g * strip_rows; e == hipSuccess && y0 < region.one_past_max_y; y0 += strip_rows * count) {
-            const int64_t y1 = std::min<int64_t>(region.one_past_max_y, count == 1 ? region.one_past_max_y : y0 + strip_rows);
-            const size_t off = static_cast<size_t>(y0) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x);
-            if (ppm_body) { // whole rows of text are contiguous
-                e = hipMemcpy(ppm_body + off * 12, d.text + off * 12, static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * 12, hipMemcpyDeviceToHost);
-                if (count == 1) break;
-                continue;
+        uint64_t h[RT_STATS_COUNT] = {0};
+        if (e == hipSuccess && d.pinned != nullptr) {
+            size_t at = 0;
+            for (int pass = 0; pass < ((o.linear_out && image_data) ? 2 : 1); ++pass) {
+                char *dst = ppm_body ? ppm_body : reinterpret_cast<char *>(pass == 0 ? image_data : o.linear_out);
+                for_each_span(g, [&](int64_t y0, int64_t y1) {
+                    const char *from = static_cast<const char *>(d.pinned) + at;
+                    if (ppm_body || row_bytes == pitch) { // whole rows
+                        std::memcpy(dst + static_cast<size_t>(y0) * static_cast<size_t>(width) * px_bytes, from, static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * px_bytes);
+                    } else {
+                        for (int64_t y = y0; y < y1; ++y)
+                            std::memcpy(dst + (static_cast<size_t>(y) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x)) * sizeof(rt_v3),
+                                        from + (static_cast<size_t>(y - y0) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x)) * sizeof(rt_v3), row_bytes);
+                    }
+                    at += static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * px_bytes;
+                    return true;
+                });
             }
-            e = hipMemcpy2D(image_data + off, pitch, reinterpret_cast<rt_v3 *>(d.image) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
-            if (e == hipSuccess && o.linear_out)
-                e = hipMemcpy2D(o.linear_out + off, pitch, reinterpret_cast<rt_v3 *>(d.linear) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
-            if (count == 1) break;
+            if (o.stats) std::memcpy(h, static_cast<const char *>(d.pinned) + d.pinned_bytes - sizeof h, sizeof h);
+        } else if (e == hipSuccess) {
+            for_each_span(g, [&](int64_t y0, int64_t y1) {
+                const size_t off = static_cast<size_t>(y0) * static_cast<size_t>(width) + static_cast<size_t>(region.min_x);
+                if (ppm_body) { // whole rows of text are contiguous
+                    const size_t row0 = static_cast<size_t>(y0) * static_cast<size_t>(width) * 12;
+                    e = hipMemcpy(ppm_body + row0, d.text + row0, static_cast<size_t>(y1 - y0) * static_cast<size_t>(width) * 12, hipMemcpyDeviceToHost);
+                    return e == hipSuccess;
+                }
+                e = hipMemcpy2D(image_data + off, pitch, reinterpret_cast<rt_v3 *>(d.image) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
+                if (e == hipSuccess && o.linear_out)
+                    e = hipMemcpy2D(o.linear_out + off, pitch, reinterpret_cast<rt_v3 *>(d.linear) + off, pitch, row_bytes, static_cast<size_t>(y1 - y0), hipMemcpyDeviceToHost);
+                return e == hipSuccess;
+            });
+            if (e == hipSuccess && o.stats) e = hipMemcpy(h, d.stats, sizeof h, hipMemcpyDeviceToHost);
         }
         if (e == hipSuccess && o.stats) {
-            uint64_t h[RT_STATS_COUNT];
-            e = hipMemcpy(h, d.stats, sizeof h, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) {
-                o.stats[RT_STAT_SEGMENTS] += h[RT_STAT_SEGMENTS];
-                o.stats[RT_STAT_SAMPLES] += h[RT_STAT_SAMPLES];
-                o.stats[RT_STAT_WAVE_ITERATIONS] += h[RT_STAT_WAVE_ITERATIONS];
-                o.stats[RT_STAT_BVH_NODES] += h[RT_STAT_BVH_NODES];
-                o.stats[RT_STAT_BVH_TESTS] += h[RT_STAT_BVH_TESTS];
-                o.stats[7] += h[7]; // diagnostic builds only
-                const int64_t ns = rt_world_last_kernel_ns(d.world);
-                if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
-            }
+            o.stats[RT_STAT_SEGMENTS] += h[RT_STAT_SEGMENTS];
+            o.stats[RT_STAT_SAMPLES] += h[RT_STAT_SAMPLES];
+            o.stats[RT_STAT_WAVE_ITERATIONS] += h[RT_STAT_WAVE_ITERATIONS];
+            o.stats[RT_STAT_BVH_NODES] += h[RT_STAT_BVH_NODES];
+            o.stats[RT_STAT_BVH_TESTS] += h[RT_STAT_BVH_TESTS];
+            o.stats[7] += h[7]; // diagnostic builds only
+            const int64_t ns = rt_world_last_kernel_ns(d.world);
+            if (ns > 0) o.stats[RT_STAT_KERNEL_NS] = std::max<uint64_t>(o.stats[RT_STAT_KERNEL_NS], static_cast<uint64_t>(ns));
         }
         if (e != hipSuccess) result = fail(RT_ERR_DEVICE, "collecting from device %d failed: %s", d.device, hipGetErrorString(e));
     }
