@@ -1143,7 +1143,7 @@ hipError_t launch_clear_queue(uint32_t *queue, hipStream_t stream) {
 }
 
 hipError_t launch_order_sum(const ReduceParams &p, bool first, hipStream_t stream) {
-    if (p.map.n_tiles <= 0 || p.chunks <= 0) return hipSuccess;
+    if (p.map.n_tiles <= 0 || (p.chunks <= 0 && !first)) return hipSuccess; // no samples at all: the first sum still writes zeros
     hipLaunchKernelGGL(order_sum_kernel, pixel_grid(p.map), dim3(256), 0, stream, p, first ? 1 : 0);
     return hipGetLastError();
 }

@@ -818,3 +818,64 @@ def test_one_shot_calls_reuse_and_replace_what_they_cache(rt, oracle):
     image = np.zeros((h, w, 3))
     rt.render_region(image, (0, 0, w, h), cam, sph, mat, seed=3)   # without linear_out this time
     assert np.array_equal(image, ref["image"])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_mixed_equals_f64_kernel_on_adversarial_worlds(rt, block):
+    """Soak of the mixed mode's filter on the GPU: worlds from millimetres to tens of kilometres across, huge next to
+    tiny spheres, nested and coincident shells, a negative radius, cameras from inside the cloud to a thousand world
+    sizes away, with and without depth of field -- the mixed image and segment count must be the f64 kernel's."""
+    rng = np.random.default_rng(4242 + block)
+    for case in range(10):
+        scale = 10.0 ** rng.uniform(-3.0, 4.0)
+        n = int(rng.choice([3, 8, 33, 120]))
+        mat = np.zeros(6, dtype=rt.MATERIAL_DTYPE)
+        mat["type"] = [0, 1, 2, 2, int(rng.choice([3, 4, 5])), 0]
+        mat["albedo"] = rng.uniform(0.1, 0.95, size=(6, 3))
+        mat["param1"] = [0.0, rng.uniform(0.0, 1.0), 1.5, 1.0 / 1.5, rng.uniform(0.0, 0.4), 0.0]
+        sph = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+        sph["center"] = rng.normal(size=(n, 3)) * scale
+        sph["radius"] = scale * 10.0 ** rng.uniform(-2.5, 0.3, size=n)
+        sph["material_index"] = rng.integers(0, 6, size=n)
+        sph["center"][1] = sph["center"][0]                        # glass shell and bubble
+        sph["radius"][1] = 0.8 * sph["radius"][0]
+        sph["material_index"][0], sph["material_index"][1] = 2, 3
+        sph[2] = sph[0]                                             # coincident duplicate
+        if n > 3:
+            sph["radius"][3] = -sph["radius"][3]                    # the reference allows it: the normal flips (main.odin:555)
+            sph["center"][4] = (0.0, -300.0 * scale, 0.0)           # ground far larger than everything else
+            sph["radius"][4] = 298.0 * scale
+        cs, _, _ = rt.build_dev_scene(int(rng.choice([32, 48])))
+        dist = scale * 10.0 ** rng.uniform(-0.5, 3.0)
+        eye = rng.normal(size=3)
+        eye *= dist / np.linalg.norm(eye)
+        target = rng.normal(size=3) * scale * 0.3
+        cs.position = rt.V3(*eye)
+        right, up, fwd = rt.lookat(tuple(eye), tuple(target), (0.0, 1.0, 0.0))
+        cs.right, cs.up, cs.forward = rt.V3(*right), rt.V3(*up), rt.V3(*fwd)
+        cs.focus_distance = float(np.linalg.norm(eye - target))
+        cs.vfov = float(min(0.3, 2.5 * scale / dist / 6.28))
+        cs.depth_of_field_angle = float(rng.choice([0.0, 0.002]))
+        cs.samples_per_pixel = 6
+        cs.max_ray_bounces = int(rng.choice([3, 50]))
+        cam = rt.calculate_camera_render_data(cs)
+        seed = int(rng.integers(0, 2 ** 62))
+        m, lin_m, st_m = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=rt.PRECISION_MIXED)
+        d, lin_d, st_d = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=rt.PRECISION_F64, sample_chunks=1)
+        assert np.array_equal(lin_m, lin_d) and np.array_equal(m, d), (block, case, scale, dist)
+        assert int(st_m[0]) == int(st_d[0]), (block, case)
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2, 3])
+def test_zero_samples_overwrite_with_zero(rt, precision):
+    """rt_render_accumulate overwrites its pixels with the sum of its samples' colours: of no samples, zero"""
+    import torch
+    cs, cam, sph, mat = scene(rt, "dev", 40, 1)
+    w, h = cs.image_width, cs.image_height
+    world = rt.World(sph, mat)
+    dtype = {0: torch.int64, 1: torch.float64, 2: torch.float32, 3: torch.float64}[precision]
+    acc = torch.full((h, w, 3), 7, dtype=dtype, device="cuda:0")
+    world.render_accumulate(cam, w, h, acc.data_ptr(), precision=precision, sample_begin=3, sample_count=0, region=(8, 8, 32, 16))
+    torch.cuda.synchronize()
+    assert bool((acc[8:16, 8:32] == 0).all()) and bool((acc[:8] == 7).all()) and bool((acc[16:] == 7).all())
+    world.close()

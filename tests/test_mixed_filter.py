@@ -184,3 +184,39 @@ def test_far_camera_and_scaled_worlds(rt, oracle):
     b = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED, seed=9, threads=4)
     assert int(b["stats"][6]) == 0 and np.array_equal(a["image"], b["image"])
     assert int(a["stats"][0]) > w * h * 4 * 1.2      # the camera does see the spheres
+
+
+def test_adversarial_worlds_audit(rt, oracle):
+    """the CPU audit of the filter (every dropped sphere re-tested in f64) on worlds of extreme proportions: a ground 300
+    world sizes large under tiny spheres, a negative radius, cameras near and three orders of magnitude away"""
+    rng = np.random.default_rng(99)
+    for case in range(12):
+        scale = 10.0 ** rng.uniform(-3.0, 4.0)
+        n = int(rng.choice([8, 40]))
+        mat = np.zeros(4, dtype=rt.MATERIAL_DTYPE)
+        mat["type"] = [0, 1, 2, 2]
+        mat["albedo"] = rng.uniform(0.1, 0.95, size=(4, 3))
+        mat["param1"] = [0.0, 0.3, 1.5, 1.0 / 1.5]
+        sph = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+        sph["center"] = rng.normal(size=(n, 3)) * scale
+        sph["radius"] = scale * 10.0 ** rng.uniform(-2.5, 0.3, size=n)
+        sph["material_index"] = rng.integers(0, 4, size=n)
+        sph["radius"][3] = -sph["radius"][3]
+        sph["center"][4] = (0.0, -300.0 * scale, 0.0)
+        sph["radius"][4] = 298.0 * scale
+        cs, _, _ = rt.build_dev_scene(24)
+        dist = scale * 10.0 ** rng.uniform(-0.5, 3.0)
+        eye = rng.normal(size=3)
+        eye *= dist / np.linalg.norm(eye)
+        cs.position = rt.V3(*eye)
+        right, up, fwd = rt.lookat(tuple(eye), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        cs.right, cs.up, cs.forward = rt.V3(*right), rt.V3(*up), rt.V3(*fwd)
+        cs.focus_distance = float(dist)
+        cs.vfov = float(min(0.3, 2.5 * scale / dist / 6.28))
+        cs.depth_of_field_angle = 0.0
+        cs.samples_per_pixel = 4
+        cam = rt.calculate_camera_render_data(cs)
+        w, h = cs.image_width, cs.image_height
+        a = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=case, threads=4)
+        b = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED, seed=case, threads=4)
+        assert int(b["stats"][6]) == 0 and np.array_equal(a["image"], b["image"]), (case, scale, dist)
