@@ -324,6 +324,7 @@ def main():
         print(json.dumps(out), flush=True)
     world.close()
     if world_size > 1:
+        dist.barrier()  # rank 0 verifies and prints after the timed region: the others leave with it, not before
         dist.destroy_process_group()
 
 
