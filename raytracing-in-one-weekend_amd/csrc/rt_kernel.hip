@@ -12,6 +12,11 @@
 //   traced what.  Lanes idle only when the whole queue is empty.
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
+//   Mixed mode: f64 paths in the reference's operation order behind the throughput mode's f32 scan,
+//   used as a filter with an error margin that never drops a sphere the f64 test would hit (the
+//   bound is derived at the scan).  Lanes pool work as in throughput mode; every sample's colour is
+//   stored to its own slot and a second kernel adds the slots in sample order, so the image is the
+//   f64 literal mode's bit for bit.
 // Closest-hit scan (throughput mode)
 //   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1},
 //   K = |c|^2 - r^2, come through the scalar cache into SGPRs, the next group of four spheres
@@ -31,10 +36,12 @@
 //   stackless traversal of a bounding-volume hierarchy with the same per-sphere test.
 //   Literal modes: records {cx, cy, cz, r*r}, the reference's expressions as written.
 // Arithmetic
-//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma calls of
-//   the throughput mode.  Division and square root are IEEE correctly rounded.  In throughput
-//   mode a vector is divided by a scalar as one reciprocal and three products; everything else
-//   follows the reference's operation order.
+//   Compiled with -ffp-contract=off: the only fused operations are the explicit fma calls -- those
+//   of the throughput mode's scan and roots, and, in every mode, places where the fused form is
+//   exact and therefore returns what the reference's separate operations return (the draws, the
+//   integer form of the f64 rejection tests).  Division and square root are IEEE correctly rounded.
+//   In throughput mode a vector is divided by a scalar as one reciprocal and three products;
+//   everything else follows the reference's operation order.
 #include "rt_kernel.h"
 #include <type_traits>
 
