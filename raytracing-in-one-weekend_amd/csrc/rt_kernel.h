@@ -11,6 +11,7 @@ constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 constexpr int BVH_LDS_BLOCK_THREADS = 512; // hierarchy in LDS: eight waves share one copy
 constexpr int GROUP = 4;             // sphere records are fetched and tested four at a time
 constexpr int SCAN_STEP = 2 * GROUP;  // spheres per iteration of the scan loop (two register sets)
+constexpr int WQ_CAP = 256;          // candidates a wave queues in LDS before it evaluates them (more are evaluated early)
 constexpr int REJECTION_CAP = 64;    // bound on the two rejection-sampling loops (P(reaching it) < 1e-20)
 constexpr int LDS_MAX_SPHERES_F32 = 4088; // just under 64 KiB of float4 records per workgroup
 constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 records per workgroup

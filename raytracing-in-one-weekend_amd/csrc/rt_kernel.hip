@@ -196,9 +196,10 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 }
 
 #ifndef RT_WAVES_PER_EU
-// The mixed kernel needs 98 registers as compiled freely, two more than five waves per SIMD allow; asked for five it
-// fits (measured 1.6 % faster).  The other instantiations keep the compiler's choice (1..8 is no constraint).
-#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? 5 : 1, MIXED ? 5 : 8)))
+// The mixed kernel is compiled for four waves per SIMD: squeezed into the 96 registers of five it spills 45 of them
+// (measured, same box: 63.7 ms at five, 62.0 ms at four; without the wave queue five was 1.6 % ahead of four).  The
+// other instantiations keep the compiler's choice (1..8 is no constraint).
+#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? 4 : 1, MIXED ? 4 : 8)))
 #else
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
@@ -216,6 +217,23 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     static_assert(BVH == 0 || (FMA && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in the throughput arithmetic only");
     static_assert(!MIXED || (std::is_same<Real, double>::value && !FMA && QUEUE && FETCH == FETCH_SCALAR && BVH == 0), "the mixed mode is f64 literal arithmetic behind the scalar-fetch f32 filter");
     constexpr bool FILTER = FMA || MIXED; // the scan is the packed-f32 candidate filter
+    // Candidates of the filter go to a queue per wave in LDS and are evaluated 64 at a time by whichever lanes there
+    // are, instead of each lane evaluating its own as they come (which ran the evaluation code about four times per
+    // segment with a quarter of the lanes each time).  See `enqueue` / `flush` in the scan.
+#ifdef RT_NO_WAVE_QUEUE
+    constexpr bool WQ = false;
+#else
+    constexpr bool WQ = FILTER && BVH == 0 && FETCH == FETCH_SCALAR;
+#endif
+    __shared__ uint32_t wq_entry[WQ ? WAVES_PER_BLOCK : 1][WQ ? WQ_CAP : 1];                    // (owner lane << 24) | sphere
+    __shared__ unsigned long long wq_best[WQ ? WAVES_PER_BLOCK : 1][WQ ? 64 : 1];             // per owner lane: smallest key so far
+    __shared__ unsigned long long wq_val[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? WQ_CAP : 1]; // mixed: the entries' roots
+    __shared__ uint32_t wq_besti[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? 64 : 1];  // mixed: lowest sphere index among equal roots
+    const int wave_in_block = threadIdx.x >> 6;
+    if constexpr (WQ) {
+        wq_best[wave_in_block][threadIdx.x & 63] = ~0ull;
+        if constexpr (MIXED) wq_besti[wave_in_block][threadIdx.x & 63] = ~0u;
+    }
     using R4 = typename Rec4<Real>::type;
     const R4 *__restrict__ g_rec = static_cast<const R4 *>(P.sphere_rec);
     const int n = P.n_spheres; // padded count, a multiple of SCAN_STEP
@@ -479,6 +497,97 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             }
             pend = -1;
         };
+        // ---- wave queue (WQ): the order in which a lane's candidates are evaluated does not matter.  For one sphere
+        // ray_sphere_intersection (main.odin:250-261) returns v = the near root if it is >= t_min, else the far root if
+        // that is >= t_min -- provided v < t_max; and since t_max only ever shrinks to the smallest v seen, the loop of
+        // main.odin:540-546 ends with the smallest v over all spheres, the lowest index among equal ones (strict `<`).
+        // So every candidate is evaluated on its own, by any lane, and the results are combined per owner with a minimum.
+        uint32_t qcount = 0; // entries queued by this wave (wave-uniform)
+        auto bperm = [&](const int owner, const float x) -> float { return __int_as_float(__builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(x))); };
+        auto bperm_d = [&](const int owner, const double x) -> double {
+            const int lo = __builtin_amdgcn_ds_bpermute(owner << 2, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(owner << 2, __double2hiint(x));
+            return __hiloint2double(hi, lo);
+        };
+        auto flush = [&]() {
+            if constexpr (WQ) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // lanes whose work ran out have left the loop: the entries are dealt to the lanes still here
+                const unsigned long long workers = __builtin_amdgcn_ballot_w64(true);
+                const uint32_t n_workers = static_cast<uint32_t>(__builtin_popcountll(workers)), me = rank_in(workers);
+                for (uint32_t base = 0; base < qcount; base += n_workers) {
+#ifdef RT_DIAG_COUNTERS
+                    if (me == 0u) ++diag_resolves; // one lane per execution by the wave
+#endif
+                    const bool have = base + me < qcount;
+                    const uint32_t e = have ? wq_entry[wave_in_block][base + me] : 0u;
+                    const int owner = static_cast<int>(e >> 24), sph = static_cast<int>(e & 0xffffffu);
+                    const R4 sp = static_cast<const R4 *>(P.sphere_center)[sph]; // {centre, r*r}
+                    if constexpr (FMA) {
+                        // the owner's ray, then the roots from the centre-to-line vector as in `resolve`
+                        const float ox = bperm(owner, ro.x), oy = bperm(owner, ro.y), oz = bperm(owner, ro.z);
+                        const float dx = bperm(owner, rd.x), dy = bperm(owner, rd.y), dz = bperm(owner, rd.z), ia = bperm(owner, inv_a);
+                        const float ocx = sp.x - ox, ocy = sp.y - oy, ocz = sp.z - oz;
+                        const float q = fma_rn(ocz, dz, fma_rn(ocy, dy, ocx * dx)) * ia;
+                        const float lx = fma_rn(-q, dx, ocx), ly = fma_rn(-q, dy, ocy), lz = fma_rn(-q, dz, ocz);
+                        const float D = sp.w - fma_rn(lz, lz, fma_rn(ly, ly, lx * lx));
+                        if (have && D >= 0.0f) {
+                            const float sq = sqrt_rn(D * ia);
+                            float v = q - sq;
+                            if (!(v >= t_min)) v = q + sq;
+                            if (v >= t_min) atomicMin(&wq_best[wave_in_block][owner], (static_cast<unsigned long long>(__float_as_uint(v)) << 32) | static_cast<unsigned long long>(sph));
+                        }
+                    } else {
+                        // ray_sphere_intersection as written (main.odin:245-261) in f64 on the owner's ray
+                        const double ox = bperm_d(owner, ro.x), oy = bperm_d(owner, ro.y), oz = bperm_d(owner, ro.z);
+                        const double dx = bperm_d(owner, rd.x), dy = bperm_d(owner, rd.y), dz = bperm_d(owner, rd.z), oa = bperm_d(owner, a);
+                        const double ocx = sp.x - ox, ocy = sp.y - oy, ocz = sp.z - oz;
+                        const double h = dx * ocx + dy * ocy + dz * ocz;
+                        const double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                        const double disc = h * h - oa * cc;
+                        unsigned long long vbits = ~0ull;
+                        if (have && !(disc < 0.0)) {
+                            const double sq = sqrt_rn(disc);
+                            double v = (h - sq) / oa;
+                            if (!(v >= t_min)) v = (h + sq) / oa;
+                            if (v >= t_min) vbits = static_cast<unsigned long long>(__double_as_longlong(v));
+                        }
+                        if (have) {
+                            wq_val[wave_in_block][base + me] = vbits;
+                            if (vbits != ~0ull) atomicMin(&wq_best[wave_in_block][owner], vbits);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if constexpr (MIXED) {
+                    // among the entries that reached their owner's smallest root, the lowest sphere index
+                    for (uint32_t base = 0; base < qcount; base += n_workers) {
+                        if (base + me < qcount) {
+                            const uint32_t e = wq_entry[wave_in_block][base + me];
+                            const unsigned long long vbits = wq_val[wave_in_block][base + me];
+                            if (vbits != ~0ull && vbits == wq_best[wave_in_block][e >> 24]) atomicMin(&wq_besti[wave_in_block][e >> 24], e & 0xffffffu);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const unsigned long long vbits = wq_best[wave_in_block][lane];
+                    const uint32_t bi = wq_besti[wave_in_block][lane];
+                    wq_best[wave_in_block][lane] = ~0ull;
+                    wq_besti[wave_in_block][lane] = ~0u;
+                    if (vbits != ~0ull) {
+                        const Real v = static_cast<Real>(__longlong_as_double(static_cast<long long>(vbits)));
+                        if (v < closest) { closest = v; hit = static_cast<int>(bi); }
+                    }
+                } else {
+                    const unsigned long long key = wq_best[wave_in_block][lane];
+                    wq_best[wave_in_block][lane] = ~0ull;
+                    if (key != ~0ull) {
+                        const Real v = static_cast<Real>(__uint_as_float(static_cast<uint32_t>(key >> 32)));
+                        if (v < closest) { closest = v; hit = static_cast<int>(key & 0xffffffu); }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qcount = 0u;
+            }
+        };
         // the uncommon continuation for one sphere: some lane's line meets it
         float behind = 0.0f; // mixed mode: h below -behind is certainly negative (set with the filter's per-ray values)
         skip_start = false;
@@ -493,6 +602,19 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // Mixed mode: only when both signs are certain despite the f32 rounding.
                 const bool ahead = MIXED ? !((h < T(-behind)) && ((cc > T(0)) || (skip_start && i == start_sphere))) : ((h > T(0)) || (cc < T(0)));
                 const bool cand = meets && ahead && (!FMA || i != start_sphere);
+                if constexpr (WQ) {
+                    const unsigned long long cmask = __builtin_amdgcn_ballot_w64(cand);
+                    if (cmask != 0ull) {
+                        const uint32_t n_new = static_cast<uint32_t>(__builtin_popcountll(cmask));
+                        if (qcount + n_new > static_cast<uint32_t>(WQ_CAP)) flush();
+                        if (cand) {
+                            wq_entry[wave_in_block][qcount + rank_in(cmask)] = (static_cast<uint32_t>(lane) << 24) | static_cast<uint32_t>(i);
+                            RT_DIAG_COUNT(diag_parked);
+                        }
+                        qcount += n_new;
+                    }
+                    return;
+                }
                 if (__builtin_amdgcn_ballot_w64(cand && pend >= 0) != 0ull) {
                     if (pend >= 0) resolve();
                 }
@@ -749,7 +871,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 #ifdef RT_DIAG_PHASES
         ph_in = __builtin_amdgcn_s_memtime();
 #endif
-        if (pend >= 0) resolve();
+        if constexpr (WQ) { if (qcount != 0u) flush(); }
+        else if (pend >= 0) resolve();
 #ifdef RT_DIAG_PHASES
         ph_slow += __builtin_amdgcn_s_memtime() - ph_in;
 #endif

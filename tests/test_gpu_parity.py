@@ -879,3 +879,28 @@ def test_zero_samples_overwrite_with_zero(rt, precision):
     torch.cuda.synchronize()
     assert bool((acc[8:16, 8:32] == 0).all()) and bool((acc[:8] == 7).all()) and bool((acc[16:] == 7).all())
     world.close()
+
+
+@pytest.mark.parametrize("precision", [0, 3])
+def test_many_candidates_per_ray_overflow_the_wave_queue(rt, oracle, precision):
+    """300 nested and overlapping spheres around the camera's line of sight: every ray's line meets hundreds of them, so a
+    wave's candidate queue (256 entries) overflows many times per segment and is evaluated early; the image must not care."""
+    rng = np.random.default_rng(5)
+    n = 300
+    mat = np.zeros(3, dtype=rt.MATERIAL_DTYPE)
+    mat["type"] = [0, 2, 1]
+    mat["albedo"] = [(0.7, 0.6, 0.5), (1.0, 1.0, 1.0), (0.8, 0.8, 0.9)]
+    mat["param1"] = [0.0, 1.5, 0.1]
+    sph = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+    sph["center"] = rng.normal(size=(n, 3)) * 0.3 + np.array([0.0, 0.0, -1.0])
+    sph["radius"] = rng.uniform(0.4, 3.0, size=n)            # most contain the camera at (-2, 2, 1) or loom over it
+    sph["material_index"] = rng.integers(0, 3, size=n)
+    cs, _, _ = rt.build_dev_scene(40)
+    cs.samples_per_pixel = 3
+    cs.max_ray_bounces = 8
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1 if precision == 3 else precision, seed=8, threads=8)
+    image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=8, precision=precision)
+    assert np.array_equal(image, ref["image"]) and np.array_equal(linear, ref["linear"])
+    assert int(stats[0]) == int(ref["stats"][0])
