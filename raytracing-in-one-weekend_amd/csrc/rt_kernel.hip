@@ -25,12 +25,13 @@
 //   (main.odin:245-249 with the squares expanded and the per-ray and per-sphere parts
 //   hoisted), all as packed instructions on two spheres at once; a group of four spheres
 //   shares one compare.  Only when some lane's line meets a sphere of the group does the wave
-//   leave the straight-line code; such a lane parks the sphere's index, and the roots -- from
-//   the centre-to-line vector, whose rounding scales with the sphere and not with its distance
-//   -- and the range tests of main.odin:250-261 are evaluated later, for all parked lanes at
-//   once, when a lane needs its slot again or the scan ends.  A lane's candidates are still
-//   resolved in sphere order with the shrinking t_max of main.odin:541-545, so results equal
-//   the straight loop's.  The sphere a scattered segment starts on is tested before the scan
+//   leave the straight-line code; such a lane queues (lane, sphere) in a per-wave queue in LDS, and
+//   the roots -- from the centre-to-line vector, whose rounding scales with the sphere and not with
+//   its distance -- and the range tests of main.odin:250-261 are evaluated later, 64 entries at a
+//   time by whichever lanes are at hand, each result going to its owner through an LDS atomic
+//   minimum (the loop of main.odin:540-546 ends with the smallest accepted root, lowest index among
+//   equals, whatever the order of evaluation).  The literal modes park one sphere per lane instead
+//   and evaluate it when the lane needs the slot again, in sphere order with the shrinking t_max.  The sphere a scattered segment starts on is tested before the scan
 //   with c = 0 (in f64 the reference sees |c| ~ 1e-15 there; in f32 the rounding of c would
 //   produce spurious self-intersections).  BVH variants replace the list by a per-lane,
 //   stackless traversal of a bounding-volume hierarchy with the same per-sphere test.
