@@ -68,8 +68,8 @@ def parse():
         args.width = 1200 if args.gpus == 1 else 3840
     if args.weak:
         args.partition = "samples"
-    if args.fetch.startswith("bvh"):
-        args.precision = "f32"
+    if args.fetch.startswith("bvh") and args.precision == "f64":
+        ap.error("--fetch bvh serves --precision f32 and mixed (the f64 image at the hierarchy's speed)")
     if args.partition == "samples" and args.gpus > 1 and args.precision != "f32":
         ap.error("--partition samples adds accumulators across ranks, which is exact only for --precision f32 (Q32.32); use --partition rows")
     return args
@@ -260,7 +260,7 @@ def main():
         # f64 sums follow the chunking: one chunk = strict sample order (what the mixed mode produces); an f64 run is re-rendered with its own chunking
         chunks = 1 if mode == "mixed" else args.chunks
         rt.render_region(whole, (0, 0, w, h), rt.calculate_camera_render_data(cs), sph, mat, seed=1, device=local_rank,
-                         precision=precisions[against], sphere_fetch=fetch, sample_chunks=chunks)
+                         precision=precisions[against], sphere_fetch=fetch if against == mode else rt.FETCH_AUTO, sample_chunks=chunks)
         cs.samples_per_pixel = args.spp
         return bool(np.array_equal(frame.cpu().numpy(), whole)), f"rt_render_region, {against} kernel, one call, bitwise"
 
@@ -298,7 +298,7 @@ def main():
             gathers = m["bvh_nodes"] + 2 * m["bvh_tests"]
             out["bvh"] = {"boxes_per_segment": m["bvh_nodes"] / max(1, m["segments"]), "sphere_tests_per_segment": m["bvh_tests"] / max(1, m["segments"])}
             out["roofline"] = {"bound": "vl1d_gather", "achieved": gathers / m["kernel_s"] / 1e9, "peak": GATHER_PEAK_G, "unit": "Ggather/s",
-                               "frac": gathers / m["kernel_s"] / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>",
+                               "frac": gathers / m["kernel_s"] / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>" if args.precision == "f32" else "render_kernel<double, f32 filter, bvh> + order_sum_kernel",
                                "kernel_ms": m["kernel_s"] * 1e3, "gathers_per_launch": gathers, "sphere_tests_per_launch": m["bvh_tests"]}
             out["pct_fp32_peak"] = None
         if not args.no_verify:

@@ -115,8 +115,9 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 #define RT_FETCH_SCALAR 1 /* list scan, records through scalar-cache loads into SGPRs              */
 #define RT_FETCH_LDS 2    /* list scan, SoA records staged once per workgroup into LDS, broadcast  */
 #define RT_FETCH_BVH 3    /* bounding-volume hierarchy over the spheres instead of the list (the
-                             TODO at main.odin:559); RT_PRECISION_F32 only; the image is the list
-                             scan's bit for bit, RT_STAT_SPHERE_TESTS counts the tests carried out.
+                             TODO at main.odin:559); RT_PRECISION_F32 and RT_PRECISION_MIXED; the image is
+                             the list scan's bit for bit (with RT_PRECISION_MIXED: the f64 image),
+                             RT_STAT_SPHERE_TESTS counts the tests carried out.
                              A hierarchy of at most 1280 nodes (about 640 spheres) is staged into LDS  */
 #define RT_FETCH_BVH_GLOBAL 4 /* the same with the hierarchy read from global memory whatever its size
                              (what RT_FETCH_BVH does for larger worlds)                              */

@@ -108,9 +108,9 @@ struct rt_world_s {
     void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
     int32_t *material_type = nullptr;
     // RT_FETCH_BVH: built and uploaded on first use from the host copies kept here
-    std::vector<float> h_rec32, h_k, h_rad32, h_rad32inv;
+    std::vector<float> h_rec32, h_k, h_km, h_rad32, h_rad32inv; // h_km: K lowered for the mixed filter
     std::vector<int32_t> h_material;
-    void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr;
+    void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_spheres_m = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr; // _m: leaf records with the mixed mode's lowered K
     int32_t bvh_n_nodes = 0;
     bool bvh_built = false;
     rtk::BvhHost bvh_host;                      // grid and big-sphere list (node and sphere vectors are released after upload)
@@ -288,7 +288,8 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     rt_world *w = new rt_world_s();
     w->h_rec32.assign(rec32.begin(), rec32.begin() + 4 * ns);
     w->h_k.resize(ns);
-    for (size_t i = 0; i < ns; ++i) w->h_k[i] = rec32k[pair_slot(i, 3)];
+    w->h_km.resize(ns);
+    for (size_t i = 0; i < ns; ++i) { w->h_k[i] = rec32k[pair_slot(i, 3)]; w->h_km[i] = rec32m[pair_slot(i, 3)]; }
     w->h_rad32 = rad32; w->h_rad32inv = rad32inv; w->h_material = smat;
     w->filter_ok = filter_ok;
     w->filter_reach = static_cast<float>(reach);
@@ -344,7 +345,7 @@ int32_t rt_world_destroy(rt_world *w) {
     (void)guard.enter(w->device);
     // calls still in flight read the buffers freed below
     for (CallSlot &c : w->slots) if (c.used && c.ev_end) (void)hipEventSynchronize(c.ev_end);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec32m, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue_ring, w->bvh_nodes, w->bvh_spheres, w->bvh_lds_boxes, w->bvh_lds_links};
+    void *bufs[] = {w->rec32, w->rec32k, w->rec32m, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue_ring, w->bvh_nodes, w->bvh_spheres, w->bvh_spheres_m, w->bvh_lds_boxes, w->bvh_lds_links};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (CallSlot &c : w->slots) {
         if (c.ev_begin) (void)hipEventDestroy(c.ev_begin);
@@ -389,7 +390,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH_GLOBAL) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
     const bool bvh_global_only = sphere_fetch == RT_FETCH_BVH_GLOBAL;
     if (bvh_global_only) sphere_fetch = RT_FETCH_BVH;
-    if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32) return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32 only");
+    if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32 && precision != RT_PRECISION_MIXED) return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32 and RT_PRECISION_MIXED only");
     if (sample_begin < 0 || sample_count < 0 || sample_begin + sample_count > (int64_t(1) << 32) - 2) return fail(RT_ERR_INVALID_ARGUMENT, "samples [%lld, +%lld) outside [0, 2^32-2)", (long long)sample_begin, (long long)sample_count);
     if (cam->max_ray_bounces < 0 || cam->max_ray_bounces > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "max_ray_bounces %lld outside [0, 2^20]", (long long)cam->max_ray_bounces);
     if (sample_chunks < 0) return fail(RT_ERR_INVALID_ARGUMENT, "sample_chunks %d < 0", sample_chunks);
@@ -401,7 +402,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     // The mixed mode's filter needs a world inside its range; any other world is traced by the f64
     // kernel with one sample chunk, which is the same arithmetic and the same summation order.
     bool mixed = precision == RT_PRECISION_MIXED;
-    if (mixed && !world->filter_ok) { mixed = false; precision = RT_PRECISION_F64; sample_chunks = 1; }
+    if (mixed && !world->filter_ok) { mixed = false; precision = RT_PRECISION_F64; sample_chunks = 1; if (sphere_fetch == RT_FETCH_BVH) sphere_fetch = RT_FETCH_SCALAR; }
     if (mixed && sphere_fetch == RT_FETCH_LDS) return fail(RT_ERR_UNSUPPORTED, "RT_PRECISION_MIXED reads its filter records through the scalar cache only");
 
     const bool f64 = precision == RT_PRECISION_F64 || mixed;
@@ -459,12 +460,19 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         rtk::BvhHost &bvh = world->bvh_host;
         rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
         // a previous attempt may have failed half way: start from nothing
-        for (void **buf : {&world->bvh_nodes, &world->bvh_spheres, &world->bvh_lds_boxes, &world->bvh_lds_links})
+        for (void **buf : {&world->bvh_nodes, &world->bvh_spheres, &world->bvh_spheres_m, &world->bvh_lds_boxes, &world->bvh_lds_links})
             if (*buf) { (void)hipFree(*buf); *buf = nullptr; }
         HIP_TRY(hipMalloc(&world->bvh_nodes, std::max<size_t>(64, bvh.nodes.size() * sizeof(rtk::BvhNode))));
         HIP_TRY(hipMalloc(&world->bvh_spheres, std::max<size_t>(64, bvh.spheres.size() * sizeof(rtk::BvhSphere))));
         if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
         if (!bvh.spheres.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
+        {
+            // the same leaf records with the mixed filter's lowered K (pad records of a leaf keep theirs)
+            std::vector<rtk::BvhSphere> lowered(bvh.spheres);
+            for (rtk::BvhSphere &sp : lowered) if (sp.index >= 0 && sp.index < world->n_spheres) sp.k = world->h_km[static_cast<size_t>(sp.index)];
+            HIP_TRY(hipMalloc(&world->bvh_spheres_m, std::max<size_t>(64, lowered.size() * sizeof(rtk::BvhSphere))));
+            if (!lowered.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres_m, lowered.data(), lowered.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
+        }
         world->bvh_n_nodes = bvh.n_nodes;
         if (!bvh.lds_boxes.empty()) {
             HIP_TRY(hipMalloc(&world->bvh_lds_boxes, bvh.lds_boxes.size() * sizeof(rtk::BvhBoxLds)));
@@ -495,6 +503,10 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         for (int a = 0; a < 3; ++a) { p.bvh_origin[a] = bvh.origin[a]; p.bvh_step[a] = bvh.step[a]; }
         static_assert(sizeof(rtk::BvhSphere) == sizeof(p.bvh_big[0]), "big-sphere records are copied bytewise");
         std::memcpy(p.bvh_big, bvh.big, sizeof(rtk::BvhSphere) * static_cast<size_t>(bvh.n_big));
+        if (mixed) {
+            p.bvh_spheres = world->bvh_spheres_m;
+            for (int g = 0; g < bvh.n_big; ++g) p.bvh_big[g][3] = world->h_km[static_cast<size_t>(bvh.big[g].index)];
+        }
     }
     p.sphere_rec = mixed ? world->rec32m : (f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32));
     p.filter_reach = world->filter_reach;

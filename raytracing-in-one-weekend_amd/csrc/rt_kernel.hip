@@ -200,7 +200,11 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 // The mixed kernel is compiled for four waves per SIMD: squeezed into the 96 registers of five it spills 45 of them
 // (measured, same box: 63.7 ms at five, 62.0 ms at four; without the wave queue five was 1.6 % ahead of four).  The
 // other instantiations keep the compiler's choice (1..8 is no constraint).
-#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? 4 : 1, MIXED ? 4 : 8)))
+// Through the hierarchy the mixed kernel waits on LDS or memory rather than on the vector pipe and more waves pay
+// (same box, 300 spp: LDS form 46.3 ms at four, 47.0 at five -- 512-thread workgroups, so five is four --, 44.2 at
+// six, 65 at eight; global form 51.0 at four and six, 46.5 at five).
+#define RT_MIXED_WAVES (BVH == 2 ? 6 : (BVH == 1 ? 5 : 4))
+#define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? RT_MIXED_WAVES : 1, MIXED ? RT_MIXED_WAVES : 8)))
 #else
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
@@ -215,8 +219,8 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 //        sample order (main.odin:575).
 template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0, bool MIXED = false>
 __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
-    static_assert(BVH == 0 || (FMA && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in the throughput arithmetic only");
-    static_assert(!MIXED || (std::is_same<Real, double>::value && !FMA && QUEUE && FETCH == FETCH_SCALAR && BVH == 0), "the mixed mode is f64 literal arithmetic behind the scalar-fetch f32 filter");
+    static_assert(BVH == 0 || ((FMA || MIXED) && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in f32, by the throughput and the mixed mode");
+    static_assert(!MIXED || (std::is_same<Real, double>::value && !FMA && QUEUE && FETCH == FETCH_SCALAR), "the mixed mode is f64 literal arithmetic behind the scalar-fetch f32 filter");
     constexpr bool FILTER = FMA || MIXED; // the scan is the packed-f32 candidate filter
     // Candidates of the filter go to a queue per wave in LDS and are evaluated 64 at a time by whichever lanes there
     // are, instead of each lane evaluating its own as they come (which ran the evaluation code about four times per
@@ -716,12 +720,35 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // well beyond the rounding of the root evaluation, hence every sphere that
                 // evaluation reports as hit is reached.
                 // one sphere through the two stages of the list scan (same operations, same order)
+                float closest_up = Lim<float>::max_v; // mixed mode: `closest` rounded up to f32, for the box tests
                 auto test_sphere = [&](const float cx, const float cy, const float cz, const float K, const float r2, const int index) {
                     ++bvh_tests;
                     // stage 1: the list scan's filter
-                    const float h = fma_rn(cz, rd.z, fma_rn(cy, rd.y, fma_rn(cx, rd.x, -d_o)));
-                    const float m = fma_rn(K, a, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
+                    const float h = fma_rn(cz, fd.z, fma_rn(cy, fd.y, fma_rn(cx, fd.x, -d_o)));
+                    const float m = fma_rn(K, fa, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
                     const float disc = fma_rn(h, h, -m);
+                    if constexpr (MIXED) {
+                        // the conservative form (K carries the sphere's share of the margin, aoo the ray's), then
+                        // ray_sphere_intersection as written (main.odin:245-261) in f64 and the caller's strict `<`
+                        // (:542-545); equal roots go to the lower list index, which the list reaches first
+                        (void)r2;
+                        if (disc < 0.0f) return; // a NaN keeps the sphere
+                        if ((h < -behind) && ((m > 0.0f) || (skip_start && index == start_sphere))) return;
+                        const R4 sp = static_cast<const R4 *>(P.sphere_center)[index]; // {centre, r*r}
+                        const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
+                        const Real hh = rd.x * ocx + rd.y * ocy + rd.z * ocz;
+                        const Real cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                        const Real dd = hh * hh - a * cc;
+                        if (dd < Real(0)) return;
+                        const Real sq = sqrt_rn(dd);
+                        Real root = (hh - sq) / a;
+                        if (!(root >= t_min)) root = (hh + sq) / a;
+                        if (!(root >= t_min)) return;
+                        if (root < closest || (root == closest && index < hit)) {
+                            closest = root; hit = index;
+                            closest_up = __double2float_ru(root);
+                        }
+                    } else {
                     if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) return;
                     // stage 2: the roots of `resolve`
                     const float ocx = cx - ro.x, ocy = cy - ro.y, ocz = cz - ro.z;
@@ -735,6 +762,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     if (root < t_min) return;
                     // in list order the first sphere of the smallest root wins; the start sphere was tested before the list
                     if (root < closest || (root == closest && hit != start_sphere && index < hit)) { closest = root; hit = index; }
+                    }
                 };
                 // spheres kept outside the hierarchy (far larger than the rest): every segment tests them
                 for (int g = 0; g < P.bvh_n_big; ++g)
@@ -744,19 +772,31 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 #ifdef RT_DIAG_BVH_ONE_ORDER
                     0;
 #else
-                    (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
+                    (fd.x < 0.0f ? 1 : 0) | (fd.y < 0.0f ? 2 : 0) | (fd.z < 0.0f ? 4 : 0);
 #endif
                 const float4 *__restrict__ leaves = static_cast<const float4 *>(P.bvh_spheres);
                 // box corner = origin + q*step, so its slab parameter (corner - o)/d is q*A + B
-                const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
-                const float ax = P.bvh_step[0] * ix, ay = P.bvh_step[1] * iy, az = P.bvh_step[2] * iz;
-                const float bx = (P.bvh_origin[0] - ro.x) * ix, by = (P.bvh_origin[1] - ro.y) * iy, bz = (P.bvh_origin[2] - ro.z) * iz;
+                const float ix = 1.0f / fd.x, iy = 1.0f / fd.y, iz = 1.0f / fd.z;
+                float ax = P.bvh_step[0] * ix, ay = P.bvh_step[1] * iy, az = P.bvh_step[2] * iz;
+                float bx = (P.bvh_origin[0] - fo.x) * ix, by = (P.bvh_origin[1] - fo.y) * iy, bz = (P.bvh_origin[2] - fo.z) * iz;
                 // The slab parameters below are off by at most 4 u (|q A| + |B|) each (u = 2^-24: the reciprocal, the two
                 // products, the difference origin - o and the fused operation), which for an origin far from the scene
                 // exceeds what the padding of the boxes absorbs.  The interval test is widened by 2^-20 of the largest
                 // |q| |A| + |B| over the axes the ray moves along, so no box whose exact test succeeds is skipped.
-                auto slack_of = [](const float a, const float b) { const float e = fma_rn(65535.0f, abs_rn(a), abs_rn(b)); return (e < Lim<float>::max_v) ? e : 0.0f; };
-                const float box_slack = 9.5367431640625e-07f * max_num(max_num(slack_of(ax, bx), slack_of(ay, by)), slack_of(az, bz));
+                // Mixed mode: the ray itself was rounded from f64, which moves a slab parameter by up to
+                // u (|o_axis / d_axis| + |parameter|); the first term joins the sum.  An axis the ray (nearly) does not move
+                // along, |1/d_axis| > 2^60 or not a number, is left out of the test there, which only widens it, and a
+                // ray outside the filter's range visits every box.
+                float ox_i = 0.0f, oy_i = 0.0f, oz_i = 0.0f;
+                if constexpr (MIXED) {
+                    const float qnan = __int_as_float(0x7fc00000);
+                    if (!(abs_rn(ix) <= 1.152921504606847e18f)) { ax = 0.0f; bx = qnan; } else ox_i = abs_rn(fo.x * ix);
+                    if (!(abs_rn(iy) <= 1.152921504606847e18f)) { ay = 0.0f; by = qnan; } else oy_i = abs_rn(fo.y * iy);
+                    if (!(abs_rn(iz) <= 1.152921504606847e18f)) { az = 0.0f; bz = qnan; } else oz_i = abs_rn(fo.z * iz);
+                }
+                auto slack_of = [](const float a, const float b, const float c) { const float e = fma_rn(65535.0f, abs_rn(a), abs_rn(b)) + c; return (e < Lim<float>::max_v) ? e : 0.0f; };
+                float box_slack = 9.5367431640625e-07f * max_num(max_num(slack_of(ax, bx, ox_i), slack_of(ay, by, oy_i)), slack_of(az, bz, oz_i));
+                if constexpr (MIXED) { if (behind == Lim<float>::max_v) box_slack = Lim<float>::max_v; } // the ray is outside the filter's range
                 // does the segment [0, closest] meet the box {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16}?
                 // A NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box.
                 auto meets_box = [&](const uint32_t w0, const uint32_t w1, const uint32_t w2) -> bool {
@@ -768,7 +808,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     const float ty0 = fma_rn(static_cast<float>(w0 >> 16), ay, by), ty1 = fma_rn(static_cast<float>(w2 & 0xffffu), ay, by);
                     const float tz0 = fma_rn(static_cast<float>(w1 & 0xffffu), az, bz), tz1 = fma_rn(static_cast<float>(w2 >> 16), az, bz);
                     const float t_in = max_num(max_num(min_num(tx0, tx1), min_num(ty0, ty1)), max_num(min_num(tz0, tz1), 0.0f));
-                    const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), closest));
+                    float t_max_f;
+                    if constexpr (MIXED) t_max_f = closest_up; else t_max_f = closest;
+                    const float t_out = min_num(min_num(max_num(tx0, tx1), max_num(ty0, ty1)), min_num(max_num(tz0, tz1), t_max_f));
                     return t_in <= t_out + box_slack;
                 };
                 auto test_leaf = [&](const int first, const int count) {
@@ -1248,7 +1290,15 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
         break;
     case ARITH_MIXED: {
         const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (static_cast<int64_t>(p.n_items) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
-        launch_k(render_kernel<double, false, FETCH_SCALAR, true, 0, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        if (fetch == FETCH_BVH && p.bvh_lds_boxes != nullptr) {
+            // as in the throughput mode; this instantiation is built for six waves per SIMD: three workgroups of 512 per CU
+            const size_t lds_bytes = static_cast<size_t>(p.bvh_n_nodes) * 48;
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(6 * 256 / BVH_LDS_BLOCK_THREADS, (160 * 1024) / std::max<size_t>(lds_bytes, 1))));
+            const int fit = std::max(1, resident_blocks / 8 * per_cu);
+            const int wanted = static_cast<int>((static_cast<int64_t>(p.n_items) + BVH_LDS_BLOCK_THREADS / 64 - 1) / (BVH_LDS_BLOCK_THREADS / 64));
+            hipLaunchKernelGGL((render_kernel<double, false, FETCH_SCALAR, true, 2, true>), dim3(std::max(1, std::min(wanted, fit))), dim3(BVH_LDS_BLOCK_THREADS, 1, 1), lds_bytes, stream, p);
+        } else if (fetch == FETCH_BVH) launch_k(render_kernel<double, false, FETCH_SCALAR, true, 1, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        else launch_k(render_kernel<double, false, FETCH_SCALAR, true, 0, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
         break;
     }
     case ARITH_F32_LITERAL:

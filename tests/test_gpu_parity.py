@@ -362,6 +362,12 @@ def test_bvh_edge_cases(rt):
     assert np.array_equal(a, b)
     with pytest.raises(rt.RtError):
         gpu_render(rt, cs, cam, sph, mat, seed=2, sphere_fetch=rt.FETCH_BVH, precision=rt.PRECISION_F64)
+    # the mixed mode through the hierarchy: the f64 kernel's image in the same situations
+    for world in (dup, big, sph[:0]):
+        a, _, st_a = gpu_render(rt, cs, cam, world, mat, seed=2, precision=rt.PRECISION_F64, sample_chunks=1)
+        for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
+            b, _, st_b = gpu_render(rt, cs, cam, world, mat, seed=2, precision=rt.PRECISION_MIXED, sphere_fetch=fetch)
+            assert np.array_equal(a, b) and int(st_a[0]) == int(st_b[0])
 
 
 @pytest.mark.parametrize("mtype", [3, 4, 5])
@@ -582,6 +588,12 @@ def test_mixed_is_bitwise_the_f64_oracle(rt, oracle, name, width, spp):
     assert np.array_equal(image, ref["image"])
     # the PPM text written on the device from the mixed accumulators
     assert rt.render_ppm(w, h, cam, sph, mat, seed=11, precision=rt.PRECISION_MIXED) == oracle.serialize_ppm(ref["image"])
+    # the same through the bounding-volume hierarchy (from LDS and from global memory): still the f64 image
+    for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
+        b_image, b_linear, b_stats = gpu_render(rt, cs, cam, sph, mat, seed=11, precision=rt.PRECISION_MIXED, sphere_fetch=fetch)
+        assert np.array_equal(b_linear, ref["linear"]) and np.array_equal(b_image, ref["image"]), fetch
+        assert int(b_stats[rt.STAT_SEGMENTS]) == int(ref["stats"][rt.STAT_SEGMENTS])
+        assert 0 < int(b_stats[rt.STAT_BVH_TESTS]) == int(b_stats[rt.STAT_SPHERE_TESTS])
 
 
 def test_mixed_sample_windows_and_splits(rt, oracle, monkeypatch):
@@ -632,6 +644,8 @@ def test_mixed_outside_the_filter_range_and_far_camera(rt, oracle):
         ref = oracle.render_region(w, h, (0, 0, w, h), cam, s2, mat, precision=rt.PRECISION_F64, seed=9, threads=4)
         image, _, stats = gpu_render(rt, c2, cam, s2, mat, seed=9, precision=rt.PRECISION_MIXED)
         assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0]), scale
+        image, _, stats = gpu_render(rt, c2, cam, s2, mat, seed=9, precision=rt.PRECISION_MIXED, sphere_fetch=rt.FETCH_BVH)
+        assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0]), scale
     far = rt.CameraSettings.from_buffer_copy(cs)
     eye = np.array([-2000.0, 2000.0, 1000.0]) * 1.7
     far.position = rt.V3(*eye)
@@ -656,9 +670,12 @@ def test_mixed_outside_the_filter_range_and_far_camera(rt, oracle):
         cfar.vfov = 0.0002 / scale
         camf = rt.calculate_camera_render_data(cfar)
         a, _, st_a = gpu_render(rt, cfar, camf, sph, mat, seed=9)
+        d, _, st_d = gpu_render(rt, cfar, camf, sph, mat, seed=9, precision=rt.PRECISION_F64, sample_chunks=1)
         for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
             b, _, st_b = gpu_render(rt, cfar, camf, sph, mat, seed=9, sphere_fetch=fetch)
             assert np.array_equal(a, b) and int(st_a[0]) == int(st_b[0]), (scale, fetch)
+            m, _, st_m = gpu_render(rt, cfar, camf, sph, mat, seed=9, sphere_fetch=fetch, precision=rt.PRECISION_MIXED)
+            assert np.array_equal(d, m) and int(st_d[0]) == int(st_m[0]), (scale, fetch)
         fin_cs, fin_cam, fin_sph, fin_mat = scene(rt, "final", 64, 2)
         a, _, _ = gpu_render(rt, cfar, camf, fin_sph, fin_mat, seed=9)
         b, _, _ = gpu_render(rt, cfar, camf, fin_sph, fin_mat, seed=9, sphere_fetch=rt.FETCH_BVH)
@@ -674,6 +691,9 @@ def test_mixed_headline_frame_against_f64_kernel_and_f32_floor(rt, oracle):
     m8, lin_m8, st_m = gpu_render(rt, cs, cam, sph, mat, seed=1, precision=rt.PRECISION_MIXED)
     d8, lin_d8, st_d = gpu_render(rt, cs, cam, sph, mat, seed=1, precision=rt.PRECISION_F64, sample_chunks=1)
     assert np.array_equal(m8, d8) and np.array_equal(lin_m8, lin_d8) and int(st_m[0]) == int(st_d[0])
+    b8, lin_b8, st_b = gpu_render(rt, cs, cam, sph, mat, seed=1, precision=rt.PRECISION_MIXED, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(b8, d8) and np.array_equal(lin_b8, lin_d8) and int(st_b[0]) == int(st_d[0])
+    print(f"final 1200x675x8 mixed: list scan {int(st_m[2]) / 1e6:.2f} ms, hierarchy {int(st_b[2]) / 1e6:.2f} ms")
     win = (588, 400, 612, 416)
     ref = oracle.render_region(w, h, win, cam, sph, mat, precision=rt.PRECISION_F64, seed=1, threads=8)
     sl = (slice(win[1], win[3]), slice(win[0], win[2]))
@@ -717,6 +737,9 @@ def test_config5_ten_thousand_spheres_1920x1080(rt, oracle):
     d, _, st_d = gpu_render(rt, cs, cam, sph, mat, seed=5, precision=rt.PRECISION_F64, region=region, sample_chunks=1)
     rs = (slice(region[1], region[3]), slice(region[0], region[2]))
     assert np.array_equal(m[rs], d[rs]) and int(st_m[0]) == int(st_d[0])
+    # through the hierarchy (too large for LDS: nodes from global memory): the whole frame in the time the list takes for the region
+    mb, _, st_mb = gpu_render(rt, cs, cam, sph, mat, seed=5, precision=rt.PRECISION_MIXED, sphere_fetch=rt.FETCH_BVH)
+    assert np.array_equal(mb[rs], d[rs]) and int(st_mb[rt.STAT_BVH_TESTS]) * 100 < int(st_mb[0]) * 10000
     ref64 = oracle.render_region(w, h, win, cam, sph, mat, precision=rt.PRECISION_F64, seed=5, threads=8)
     assert np.array_equal(m[sl], ref64["image"][sl])
 
@@ -864,6 +887,8 @@ def test_mixed_equals_f64_kernel_on_adversarial_worlds(rt, block):
         d, lin_d, st_d = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=rt.PRECISION_F64, sample_chunks=1)
         assert np.array_equal(lin_m, lin_d) and np.array_equal(m, d), (block, case, scale, dist)
         assert int(st_m[0]) == int(st_d[0]), (block, case)
+        b, lin_b, st_b = gpu_render(rt, cs, cam, sph, mat, seed=seed, precision=rt.PRECISION_MIXED, sphere_fetch=rt.FETCH_BVH if case % 2 else rt.FETCH_BVH_GLOBAL)
+        assert np.array_equal(lin_b, lin_d) and np.array_equal(b, d) and int(st_b[0]) == int(st_d[0]), ("hierarchy", block, case, scale, dist)
 
 
 @pytest.mark.parametrize("precision", [0, 1, 2, 3])

@@ -9,6 +9,7 @@ import torch
 rt = importlib.import_module("raytracing-in-one-weekend_amd")
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+fetch = {"": rt.FETCH_AUTO, "bvh": rt.FETCH_BVH, "bvh-global": rt.FETCH_BVH_GLOBAL}[os.environ.get("AB_FETCH", "")]  # AB_FETCH=bvh: through the hierarchy
 precision = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "f64": rt.PRECISION_F64}[mode]
 cs, sph, mat = rt.build_final_scene(1, 1200)
 cs.samples_per_pixel = spp
@@ -20,7 +21,7 @@ st = torch.zeros(8, dtype=torch.int64, device="cuda")
 best = None
 for k in range(4):
     st.zero_()
-    world.render_accumulate(cam, w, h, acc.data_ptr(), seed=1, precision=precision, d_stats=st.data_ptr())
+    world.render_accumulate(cam, w, h, acc.data_ptr(), seed=1, precision=precision, d_stats=st.data_ptr(), sphere_fetch=fetch)
     torch.cuda.synchronize()
     ns = world.last_kernel_ns()
     best = ns if best is None else min(best, ns)
