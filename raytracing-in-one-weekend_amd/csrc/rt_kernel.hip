@@ -31,10 +31,13 @@
 //   time by whichever lanes are at hand, each result going to its owner through an LDS atomic
 //   minimum (the loop of main.odin:540-546 ends with the smallest accepted root, lowest index among
 //   equals, whatever the order of evaluation).  The literal modes park one sphere per lane instead
-//   and evaluate it when the lane needs the slot again, in sphere order with the shrinking t_max.  The sphere a scattered segment starts on is tested before the scan
-//   with c = 0 (in f64 the reference sees |c| ~ 1e-15 there; in f32 the rounding of c would
-//   produce spurious self-intersections).  BVH variants replace the list by a per-lane,
-//   stackless traversal of a bounding-volume hierarchy with the same per-sphere test.
+//   and evaluate it when the lane needs the slot again, in sphere order with the shrinking t_max.
+//   The sphere a scattered segment starts on is tested before the scan with c = 0 (in f64 the
+//   reference sees |c| ~ 1e-15 there; in f32 the rounding of c would produce spurious
+//   self-intersections).  BVH variants replace the list by a per-lane, stackless traversal of a
+//   bounding-volume hierarchy with the same per-sphere test; in the mixed mode the traversal runs in
+//   f32 on the rounded f64 ray with its box test widened by what that rounding can move, and a
+//   leaf's spheres go through the conservative filter and then the reference's f64 test.
 //   Literal modes: records {cx, cy, cz, r*r}, the reference's expressions as written.
 // Arithmetic
 //   Compiled with -ffp-contract=off: the only fused operations are the explicit fma calls -- those
