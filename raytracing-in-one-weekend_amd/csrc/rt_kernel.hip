@@ -737,6 +737,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                         (void)r2;
                         if (disc < 0.0f) return; // a NaN keeps the sphere
                         if ((h < -behind) && ((m > 0.0f) || (skip_start && index == start_sphere))) return;
+#ifdef RT_DIAG_COUNTERS
+                        if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_parked; // one lane per execution by the wave (stats[7]; 5 and 6 hold the hierarchy's counts)
+#endif
                         const R4 sp = static_cast<const R4 *>(P.sphere_center)[index]; // {centre, r*r}
                         const Real ocx = sp.x - ro.x, ocy = sp.y - ro.y, ocz = sp.z - ro.z;
                         const Real hh = rd.x * ocx + rd.y * ocy + rd.z * ocz;
