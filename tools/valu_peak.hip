@@ -127,6 +127,64 @@ OP_KERNEL(op_rcp, "v_rcp_f32 %0, %0", "v")
 OP_KERNEL(op_cvt, "v_cvt_f32_u32 %0, %0", "v")
 OP_KERNEL(op_max, "v_max_f32 %0, %0, %1", "v")
 
+
+// packed fma whose scalar-pair operand is selected per half (op_sel): the low dword for both halves; the same with the
+// scalar pair as multiplier AND addend (one scalar operand read twice); and the plain fma that closes such a chain,
+// reading both its factors from the low half of a pair and adding into the high half
+#define PK_KERNEL(name, text)                                                                       \
+    __global__ void name(float *out, float b, float c) {                                            \
+        v2f acc[ACC / 2];                                                                           \
+        const v2f vb = {b, b * 1.0001f}, vc = {c, c * 0.9999f};                                     \
+        _Pragma("unroll") for (int i = 0; i < ACC / 2; ++i) acc[i] = v2f{threadIdx.x * 1e-6f + i, threadIdx.x * 2e-6f + i}; \
+        for (int it = 0; it < ITERS; ++it) {                                                        \
+            _Pragma("unroll") for (int i = 0; i < ACC / 2; ++i) asm volatile(text : "+v"(acc[i]) : "s"(vb), "v"(vc)); \
+        }                                                                                           \
+        float s = 0.f;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < ACC / 2; ++i) s += acc[i].x + acc[i].y;               \
+        if (s == 123.456f) out[0] = s;                                                              \
+    }
+PK_KERNEL(pk_sel_lo, "v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]")
+PK_KERNEL(pk_sel_hi, "v_pk_fma_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+PK_KERNEL(pk_same_pair, "v_pk_fma_f32 %0, %1, %0, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]")
+PK_KERNEL(pk_vgpr_sel, "v_pk_fma_f32 %0, %2, %0, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]")
+__global__ void fmac_halves(float *out, float b, float c) {
+    v2f acc[ACC];
+    (void)b; (void)c;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = v2f{threadIdx.x * 1e-6f + i, threadIdx.x * 2e-6f + i};
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(acc[i].y) : "v"(acc[i].x));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i].x + acc[i].y;
+    if (s == 123.456f) out[0] = s;
+}
+
+// the instruction mix of a one-sphere chain: three packed operations and one plain one, on independent registers
+__global__ void mix_3pk_1fma(float *out, float b, float c) {
+    v2f acc[6];
+    float pl[2];
+    const v2f vb = {b, b * 1.0001f}, vc = {c, c * 0.9999f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = v2f{threadIdx.x * 1e-6f + i, threadIdx.x * 2e-6f + i};
+    pl[0] = b; pl[1] = c;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc[3 * i]) : "s"(vb), "v"(vc));
+            asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc[3 * i + 1]) : "s"(vb), "v"(vc));
+            asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc[3 * i + 2]) : "s"(vb), "v"(vc));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(pl[i]) : "v"(b), "v"(c));
+        }
+    }
+    float s = pl[0] + pl[1];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += acc[i].x + acc[i].y;
+    if (s == 123.456f) out[0] = s;
+}
+
 template <class K> double run(K kernel, int blocks_per_cu, int threads, float *d) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -177,6 +235,20 @@ int main() {
         printf("cycles per wave64 instruction per SIMD (8 waves/SIMD):");
         for (auto &o : ops) printf("  %s %.1f", o.name, o.t * hz * 1024.0 / insts);
         printf("\n");
+    }
+    for (int waves_per_simd : {4, 8}) {
+        // cycles per wave64 instruction per SIMD of the operand-selected forms
+        const double hz = prop.clockRate * 1e3;
+        const double insts_pk = 256.0 * waves_per_simd * 4 * double(ITERS) * (ACC / 2), insts = insts_pk * 2;
+        printf("waves/SIMD %d, cycles per wave64 instruction per SIMD: v_pk_fma_f32 (SGPR pair) %.2f  op_sel low half %.2f  op_sel high half %.2f  same SGPR pair as factor and addend %.2f  VGPR pair as factor and addend, op_sel %.2f  v_fmac_f32 on the halves of a pair %.2f\n",
+               waves_per_simd, run(fma_packed_sgpr, waves_per_simd, 256, d) * hz / (insts_pk / 1024.0), run(pk_sel_lo, waves_per_simd, 256, d) * hz / (insts_pk / 1024.0),
+               run(pk_sel_hi, waves_per_simd, 256, d) * hz / (insts_pk / 1024.0), run(pk_same_pair, waves_per_simd, 256, d) * hz / (insts_pk / 1024.0),
+               run(pk_vgpr_sel, waves_per_simd, 256, d) * hz / (insts_pk / 1024.0), run(fmac_halves, waves_per_simd, 256, d) * hz / (insts / 1024.0));
+    }
+    for (int waves_per_simd : {4, 8}) {
+        const double hz = prop.clockRate * 1e3;
+        const double groups = 256.0 * waves_per_simd * 4 * double(ITERS) * 2; // groups of 3 packed + 1 plain per launch
+        printf("waves/SIMD %d: 3 v_pk_fma_f32 + 1 v_fma_f32 cost %.2f cycles per SIMD (sum of the single-instruction costs: 15.3)\n", waves_per_simd, run(mix_3pk_1fma, waves_per_simd, 256, d) * hz / (groups / 1024.0));
     }
     printf("{\"v_fma_f32_tflops\": %.2f, \"v_pk_fma_f32_tflops\": %.2f, \"sphere_mix_tflops\": %.2f, \"spec_tflops\": 157.3}\n",
            best_scalar * 1e-12, best_packed * 1e-12, best_mix * 1e-12);
