@@ -337,6 +337,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // [1..2]: 5 = dealing + camera ray, 6 = closest-hit scan without its slow path, 7 = slow path (park + resolve),
     // 1 = shading of a hit, 2 = background + end of sample
     unsigned long long ph_fresh = 0, ph_scan = 0, ph_slow = 0, ph_hit = 0, ph_end = 0, ph_t = 0, ph_in = 0;
+#ifdef RT_DIAG_FLUSH
+    unsigned long long ph_flush = 0; // with RT_DIAG_PHASES: the evaluation of the wave queue alone, reported in place of the shading time
+#endif
 #define RT_PHASE(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - ph_t; ph_t = now_; } while (0)
 #else
 #define RT_PHASE(acc) ((void)0)
@@ -518,6 +521,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         };
         auto flush = [&]() {
             if constexpr (WQ) {
+#ifdef RT_DIAG_FLUSH
+                const unsigned long long flush_t0 = __builtin_amdgcn_s_memtime();
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // lanes whose work ran out have left the loop: the entries are dealt to the lanes still here
                 const unsigned long long workers = __builtin_amdgcn_ballot_w64(true);
@@ -594,6 +600,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 qcount = 0u;
+#ifdef RT_DIAG_FLUSH
+                ph_flush += __builtin_amdgcn_s_memtime() - flush_t0;
+#endif
             }
         };
         // the uncommon continuation for one sphere: some lane's line meets it
@@ -1104,7 +1113,11 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             atomicAdd(&P.stats[5], ph_fresh);
             atomicAdd(&P.stats[6], ph_scan - ph_slow);
             atomicAdd(&P.stats[7], ph_slow);
+#ifdef RT_DIAG_FLUSH
+            atomicAdd(&P.stats[1], ph_flush);
+#else
             atomicAdd(&P.stats[1], ph_hit);
+#endif
             atomicAdd(&P.stats[2], ph_end);
         }
 #endif
