@@ -1,0 +1,75 @@
+"""RCCL on the hardware at hand: one GPU, so a process group of one rank.  The two collectives of
+raytracing-in-one-weekend_amd/multi_gpu.py -- the all-reduce (SUM) of the int64 Q32.32 accumulators of the sample
+partition and the gather of finalised f64 rows of the row partition -- run through the "nccl" backend on buffers the
+kernels have just written, and must hand them back unchanged; the frame assembled from them must equal one
+rt_render_region call.  (More ranks need more GPUs: the partition logic at 2-4 ranks is covered over gloo in
+test_distributed.py.)  Runs in a child process so that a stuck collective ends with the child."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+mg = importlib.import_module("raytracing-in-one-weekend_amd.multi_gpu")
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[2]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl"
+cs, sph, mat = rt.build_dev_scene(96)
+cs.samples_per_pixel = 6
+cam = rt.calculate_camera_render_data(cs)
+w, h = cs.image_width, cs.image_height
+world = rt.World(sph, mat)
+ref = np.zeros((h, w, 3), dtype=np.float64)
+rt.render_region(ref, (0, 0, w, h), cam, sph, mat, seed=3, precision=rt.PRECISION_F32)
+
+def trace(buf, strip_rows, strip_index, strip_count, sample_begin, sample_count):
+    world.render_accumulate(cam, w, h, buf.data_ptr(), seed=3, precision=rt.PRECISION_F32, sample_begin=sample_begin, sample_count=sample_count,
+                            strip_rows=strip_rows, strip_index=strip_index, strip_count=strip_count)
+
+def finish(buf, img, total_samples, strip_rows, strip_index, strip_count):
+    world.finalize(buf.data_ptr(), w, h, total_samples, img.data_ptr(), precision=rt.PRECISION_F32, strip_rows=strip_rows, strip_index=strip_index, strip_count=strip_count)
+
+for partition in ("samples", "rows"):
+    plan = mg.Plan(partition, 0, 1, cs.samples_per_pixel)
+    accum = torch.zeros(h, w, 3, dtype=torch.int64, device="cuda")
+    image = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    gathered = torch.full_like(image, -5.0)
+    begin, n = plan.sample_range
+    rows, index, count = plan.strips
+    trace(accum, rows, index, count, begin, n)
+    torch.cuda.synchronize()
+    before = accum.clone()
+    if partition == "samples":
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # what render_step issues at N > 1
+        torch.cuda.synchronize()
+        assert torch.equal(accum, before) and int(accum.abs().sum()) > 0
+        finish(accum, image, plan.total_spp, rows, 0, 1)
+        frame = image
+    else:
+        finish(accum, image, plan.spp, rows, index, count)
+        torch.cuda.synchronize()
+        frame = mg.RowGather(plan, image).run(dist, image, gathered)   # dist.gather of the rank's rows, then the scatter
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(h, w, 3), ref), partition
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_collectives_of_both_partitions_through_rccl_on_one_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", CHILD, ROOT, "29653"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
