@@ -326,7 +326,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // mixed mode: bound on |c| of main.odin:248 for the sphere this segment starts on (see the scan), and the
     // reach + |o| of the segment being traced, from which the next segment's bound is formed
     float start_cc_bound = 0.0f, reach_o = 0.0f;
-    bool skip_start = false;
+    int skip_sphere = -1; // mixed mode: the sphere this segment starts on when it may be dropped on the sign of h alone, else -1
     uint32_t segments = 0, started = 0;
     uint32_t bvh_nodes = 0, bvh_tests = 0; // hierarchy mode: boxes and spheres this lane tested
 #ifdef RT_DIAG_BVH
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         };
         // the uncommon continuation for one sphere: some lane's line meets it
         float behind = 0.0f; // mixed mode: h below -behind is certainly negative (set with the filter's per-ray values)
-        skip_start = false;
+        skip_sphere = -1;
         auto park = [&](const auto h, const auto cc, const auto disc, const int i) {
             using T = decltype(disc);
             // mixed mode: the filter's discriminant carries its error margin (see below), and a NaN keeps the sphere
@@ -617,8 +617,10 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
                 // (the sphere the segment starts on was tested before the scan)
                 // Mixed mode: only when both signs are certain despite the f32 rounding.
-                const bool ahead = MIXED ? !((h < T(-behind)) && ((cc > T(0)) || (skip_start && i == start_sphere))) : ((h > T(0)) || (cc < T(0)));
-                const bool cand = meets && ahead && (!FMA || i != start_sphere);
+                // (plain & and | on the lane predicates: each is a compare into a scalar mask and the combination scalar
+                // logic, where && and || would branch around the second compare)
+                const bool ahead = MIXED ? !((h < T(-behind)) & ((cc > T(0)) | (i == skip_sphere))) : ((h > T(0)) | (cc < T(0)));
+                const bool cand = meets & ahead & (!FMA | (i != start_sphere));
                 if constexpr (WQ) {
                     const unsigned long long cmask = __builtin_amdgcn_ballot_w64(cand);
                     if (cmask != 0ull) {
@@ -710,14 +712,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // certainly below -behind/2 the roots of main.odin:253-257 are <= 0 (c >= 0) or the far one is
                 // c/(h - sqrt(disc)) <= |c| / (2|h|) <= |c| / behind; below t_min the sphere cannot be hit and
                 // ray_sphere_intersection need not be evaluated for it.
-                skip_start = start_sphere >= 0 && start_cc_bound < 9.0e-4f * behind;
+                skip_sphere = (start_sphere >= 0 && start_cc_bound < 9.0e-4f * behind) ? start_sphere : -1;
                 const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f); // 2^-40, 2^40
                 if (!in_range) {
                     // every sphere is a candidate of this ray: h = 0, a*c = -1, discriminant 1
                     fd = {0.0f, 0.0f, 0.0f}; d_o = 0.0f; fa = 0.0f;
                     aox = 0.0f; aoy = 0.0f; aoz = 0.0f; aoo = -1.0f;
                     behind = Lim<float>::max_v;
-                    skip_start = false;
+                    skip_sphere = -1;
                     reach_o = Lim<float>::max_v;
                 }
             }
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                         // (:542-545); equal roots go to the lower list index, which the list reaches first
                         (void)r2;
                         if (disc < 0.0f) return; // a NaN keeps the sphere
-                        if ((h < -behind) && ((m > 0.0f) || (skip_start && index == start_sphere))) return;
+                        if ((h < -behind) && ((m > 0.0f) || (index == skip_sphere))) return;
 #ifdef RT_DIAG_COUNTERS
                         if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_parked; // one lane per execution by the wave (stats[7]; 5 and 6 hold the hierarchy's counts)
 #endif
