@@ -271,56 +271,73 @@ inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float>
     return root;
 }
 
-/* The candidate filter of the GPU mixed mode: stage 1 of ray_sphere_intersection_expanded run on
- * the f64 ray rounded to f32, with an error margin.  With u = 2^-24 and S = |center| + |o| + r the
- * f32 discriminant differs from the f64 one of main.odin:249 by at most 34 u a S^2 (8 from rounding
- * d, o, center, r to f32; 12 from h: three fused roundings plus the plain dot product d.o, doubled
- * by squaring; 12 from a*c; 2 from the last fused operation), and S^2 <= 3(|center|^2 + r^2 +
- * |o|^2).  So a*c is lowered by 2^-17 a (|center|^2 + r^2 + |o|^2) = 42.7 u a S^2: the sphere's
- * share sits in its constant Km = K - 2^-17 (|center|^2 + r^2) (rounded down), the ray's share in
- * aoo = a|o|^2 (1 - 2^-17).  A sphere is kept unless the lowered discriminant is negative; of the
- * kept ones those with h < -behind and a*c > 0 (certainly behind an origin certainly outside) are
- * dropped as well, behind = 2^-20 |d|_1 (reach + |o|_1) >= 2 * 8 u |d| S bounding twice the error of h
- * (|.|_1 the sum of absolute components, an upper bound of the length that needs no square root).
- * The sphere a scattered segment starts on is dropped under the same condition on h when its c
+/* The candidate filter of the GPU mixed mode: seven fused f32 operations per sphere on the f64 ray
+ * rounded to f32, with an error margin, so that no sphere the f64 test of main.odin:245-261 reports
+ * as hit is ever dropped.  The ray is taken as a unit direction e = d/|d| and the foot point
+ * f = o - (o.e) e of the coordinate origin on its line; then
+ *     r^2 - dist(center, line)^2 = (c.e)^2 - K + 2 c.f - |f|^2,   K = |center|^2 - r^2
+ * (= disc / a of main.odin:249), evaluated as
+ *     h = fma(cz, ez, fma(cy, ey, cx*ex)),   w = fma(cz, 2fz, fma(cy, 2fy, fma(cx, 2fx, fma(h, h, -K)))),
+ * and the sphere is kept unless w < |f|^2.  With u = 2^-24 and S = |center| + |o| + r, w - |f|^2
+ * differs from the f64 value by at most 43 u S^2: 18 from rounding d, o, center, r to f32 and from the
+ * roundings of e and f (the line moves by at most 8 u S near a sphere it meets), 10 because |e|^2 - 1
+ * and f.e are not exactly zero (at most 9 u and 13 u |o|), 10 from evaluating h and w, 4 from |f|^2,
+ * 1 from the difference.  S^2 <= 3(|center|^2 + r^2 + |o|^2), so K is lowered by 2^-16 (|center|^2 +
+ * r^2) (the record holds -K', rounded up) and |f|^2 by 2^-16 |o|^2: 85 u S^2 in all, 42 to spare.
+ * The spare part makes a second decision certain: hs = h - o.e, the center's parameter relative to
+ * the origin per unit direction, is off by at most 12 u S, so hs < -behind with behind = 2^-19
+ * (reach + |o|_1) >= 32 u S is certainly negative (|.|_1 the sum of absolute components, an upper bound
+ * of the length that needs no square root), and hs^2 > w - thr then makes c = hs^2 - disc/a of
+ * main.odin:248 certainly positive (24 u S^2 for the error of hs^2): the line meets the sphere only
+ * behind an origin outside it, both roots are negative, the sphere is dropped.
+ * The sphere a scattered segment starts on is dropped under the same condition on hs when its c
  * (main.odin:248) is known to be tiny: the origin p = o' + t d' was a root of that sphere's
  * equation, so |c| <= 64 * 2^-53 (reach + |o'|)^2 =: B (o' the previous origin; 21 units from the
- * root and the hit point, 4 from evaluating c), and with |h| >= behind/2 the roots of
- * main.odin:253-257 are <= 0 (c >= 0) or the far one is c/(h - sqrt(disc)) <= B/behind, which is
- * below t_min when B < 9e-4 behind.  The bound
+ * root and the hit point, 4 from evaluating c), and with |h| >= |d| behind/2 the roots of
+ * main.odin:253-257 are <= 0 (c >= 0) or the far one is c/(h - sqrt(disc)) <= B/(|d| behind), which is
+ * below t_min when B < 9e-4 |d| behind.  The bound
  * needs normal f32 numbers throughout: spheres with 2^-20 <= |r| and |center| + |r| <= 2^20 (else
- * the filter is not used at all), rays with 2^-40 <= a <= 2^40 and |o|^2 <= 2^40 (else the ray keeps
+ * the filter is not used at all), rays with 2^-40 <= |d|^2 <= 2^40 and |o|^2 <= 2^40 (else the ray keeps
  * every sphere). */
-struct filter_ray { expanded_ray e; float behind, reach_o; bool in_range; };
+struct filter_ray { vec3<float> e, f2; float s_o, thr, nd, behind, reach_o; bool in_range; };
 inline float sphere_constant_lowered(float cx, float cy, float cz, float radius) {
     const double c2 = static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz, r2 = static_cast<double>(radius) * radius;
-    const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 131072.0);
-    float km = static_cast<float>(lowered);
-    if (static_cast<double>(km) > lowered) km = std::nextafterf(km, -INFINITY);
-    return km;
+    const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 65536.0);
+    float kn = static_cast<float>(-lowered); /* -K' */
+    if (static_cast<double>(kn) < -lowered) kn = std::nextafterf(kn, INFINITY);
+    return kn;
 }
 inline filter_ray make_filter_ray(const ray_t<double> &r, float reach) {
     filter_ray f;
-    ray_t<float> rf{{static_cast<float>(r.origin.x), static_cast<float>(r.origin.y), static_cast<float>(r.origin.z)},
-                    {static_cast<float>(r.direction.x), static_cast<float>(r.direction.y), static_cast<float>(r.direction.z)}};
-    f.e = expand_ray(rf);
-    const float o_o = dot(rf.origin, rf.origin);
-    f.e.aoo = f.e.aoo * (1.0f - 7.62939453125e-06f);
-    f.reach_o = reach + (std::fabs(rf.origin.x) + std::fabs(rf.origin.y) + std::fabs(rf.origin.z));
-    f.behind = 9.5367431640625e-07f * (std::fabs(rf.direction.x) + std::fabs(rf.direction.y) + std::fabs(rf.direction.z)) * f.reach_o;
-    f.in_range = (f.e.a >= 9.094947017729282e-13f) && (f.e.a <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f);
+    const vec3<float> fo{static_cast<float>(r.origin.x), static_cast<float>(r.origin.y), static_cast<float>(r.origin.z)};
+    const vec3<float> fd{static_cast<float>(r.direction.x), static_cast<float>(r.direction.y), static_cast<float>(r.direction.z)};
+    const float fa = dot(fd, fd), o_o = dot(fo, fo);
+    f.nd = std::sqrt(fa);
+    const float inv_nd = 1.0f / f.nd;
+    f.e = {fd.x * inv_nd, fd.y * inv_nd, fd.z * inv_nd};
+    f.s_o = dot(fo, f.e);
+    const vec3<float> ft{std::fmaf(-f.s_o, f.e.x, fo.x), std::fmaf(-f.s_o, f.e.y, fo.y), std::fmaf(-f.s_o, f.e.z, fo.z)};
+    f.thr = std::fmaf(-1.52587890625e-05f, o_o, dot(ft, ft));
+    f.f2 = {ft.x + ft.x, ft.y + ft.y, ft.z + ft.z};
+    f.reach_o = reach + (std::fabs(fo.x) + std::fabs(fo.y) + std::fabs(fo.z));
+    f.behind = 1.9073486328125e-06f * f.reach_o;
+    f.in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f);
     if (!f.in_range) f.reach_o = FLT_MAX;
     return f;
 }
-/* on_start: the sphere is the one the segment starts on and its c is known to be below 9e-4 behind */
-inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Km, bool on_start = false) {
+/* the filter's values for one sphere: h = c.e and w (see above); Kn = -K' */
+inline void mixed_filter_values(const filter_ray &f, vec3<float> c, float Kn, float &h, float &w) {
+    h = std::fmaf(c.z, f.e.z, std::fmaf(c.y, f.e.y, c.x * f.e.x));
+    w = std::fmaf(c.z, f.f2.z, std::fmaf(c.y, f.f2.y, std::fmaf(c.x, f.f2.x, std::fmaf(h, h, Kn))));
+}
+/* on_start: the sphere is the one the segment starts on and its c is known to be below 9e-4 |d| behind */
+inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Kn, bool on_start = false) {
     if (!f.in_range) return true;
-    const expanded_ray &e = f.e;
-    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
-    const float m = std::fmaf(Km, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
-    const float disc = std::fmaf(h, h, -m);
-    if (disc < 0) return false;
-    if (h < -f.behind && (m > 0 || on_start)) return false;
+    float h, w;
+    mixed_filter_values(f, c, Kn, h, w);
+    if (w < f.thr) return false;
+    const float hs = h - f.s_o;
+    if (hs < -f.behind && (std::fmaf(hs, hs, -(w - f.thr)) > 0 || on_start)) return false;
     return true;
 }
 
@@ -451,7 +468,7 @@ template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
 
 /* ---------------------------------------------------------------- the world in Real */
 template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K, inv_radius; /* |center|^2 - r^2 and 1/r: throughput arithmetic only */
-                                        vec3<float> center32; float Km; /* mixed mode's filter record */ };
+                                        vec3<float> center32; float Km; /* mixed mode's filter record: f32 center and -K' */ };
 template <class Real> struct camera_t {
     vec3<Real> position, du, dv, top_left, dof_u, dof_v;
     Real dof_angle;
@@ -527,7 +544,7 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
             }
         } else if constexpr (MIXED) {
             const filter_ray f = make_filter_ray(ray, sc.filter_reach);
-            const bool skip_start = start_sphere >= 0 && f.in_range && start_cc_bound < 9.0e-4f * f.behind;
+            const bool skip_start = start_sphere >= 0 && f.in_range && start_cc_bound < 9.0e-4f * (f.nd * f.behind);
             next_cc_bound = 7.2e-15f * f.reach_o * f.reach_o; /* 64 * 2^-53 (reach + |o|)^2, for the segment that follows */
             for (int64_t i = 0; i < n; ++i) {
                 const bool keep = !sc.filter_ok || mixed_filter(f, sc.spheres[i].center32, sc.spheres[i].Km, skip_start && i == start_sphere);
@@ -711,20 +728,23 @@ int32_t oracle_render_region(int32_t precision, double *image, double *linear, d
 }
 
 /* The mixed mode's filter for one ray and one sphere, with its intermediate values:
- * out = {lowered discriminant, lowered a*c, h, behind, in_range (0/1), kept (0/1), bound on |c| for the next segment}.
+ * out = {lowered discriminant per unit direction w - thr, hs^2 - (w - thr) (the filter's stand-in for c of main.odin:248),
+ *        hs (the center's parameter relative to the origin), behind, in_range (0/1), kept (0/1),
+ *        bound on |c| for the next segment, |d| as the filter computes it}.
  * start_cc_bound >= 0: the sphere is the one the segment starts on, with that bound on its |c| (main.odin:248). */
 void oracle_mixed_filter(const double *o, const double *d, const double *c, double radius, double reach, double start_cc_bound, double *out) {
     ray_t<double> r{{o[0], o[1], o[2]}, {d[0], d[1], d[2]}};
     const filter_ray f = make_filter_ray(r, static_cast<float>(reach));
     const vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
-    const float Km = sphere_constant_lowered(cf.x, cf.y, cf.z, (float)radius);
-    const expanded_ray &e = f.e;
-    const float h = std::fmaf(cf.z, e.dz, std::fmaf(cf.y, e.dy, std::fmaf(cf.x, e.dx, -e.d_o)));
-    const float m = std::fmaf(Km, e.a, std::fmaf(cf.z, e.aoz, std::fmaf(cf.y, e.aoy, std::fmaf(cf.x, e.aox, e.aoo))));
-    out[0] = std::fmaf(h, h, -m); out[1] = m; out[2] = h; out[3] = f.behind; out[4] = f.in_range ? 1.0 : 0.0;
-    const bool on_start = start_cc_bound >= 0.0 && f.in_range && static_cast<float>(start_cc_bound) < 9.0e-4f * f.behind;
-    out[5] = mixed_filter(f, cf, Km, on_start) ? 1.0 : 0.0;
+    const float Kn = sphere_constant_lowered(cf.x, cf.y, cf.z, (float)radius);
+    float h, w;
+    mixed_filter_values(f, cf, Kn, h, w);
+    const float hs = h - f.s_o, dl = w - f.thr;
+    out[0] = dl; out[1] = std::fmaf(hs, hs, -dl); out[2] = hs; out[3] = f.behind; out[4] = f.in_range ? 1.0 : 0.0;
+    const bool on_start = start_cc_bound >= 0.0 && f.in_range && static_cast<float>(start_cc_bound) < 9.0e-4f * (f.nd * f.behind);
+    out[5] = mixed_filter(f, cf, Kn, on_start) ? 1.0 : 0.0;
     out[6] = 7.2e-15f * f.reach_o * f.reach_o;
+    out[7] = f.nd;
 }
 
 /* ray_sphere_intersection with explicit inputs (o, d, c are 3 doubles each) */

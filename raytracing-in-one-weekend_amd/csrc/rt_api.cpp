@@ -99,7 +99,7 @@ struct rt_world_s {
     int last_slot = -1;
     void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
     void *rec32k = nullptr;                     // {cx, cy, cz, |c|^2 - r*r}: the throughput kernel's records
-    void *rec32m = nullptr;                     // the same pairs with K lowered by the mixed mode's filter margin
+    void *rec32m = nullptr;                     // the same pairs with -K' in place of K, K' lowered by the mixed mode's filter margin
     float filter_reach = 0.0f;                  // max |c| + |r| over the spheres, rounded up
     bool filter_ok = true;                      // every sphere inside the range the filter's error bound needs
     void *rad32 = nullptr, *rad64 = nullptr;
@@ -108,7 +108,7 @@ struct rt_world_s {
     void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
     int32_t *material_type = nullptr;
     // RT_FETCH_BVH: built and uploaded on first use from the host copies kept here
-    std::vector<float> h_rec32, h_k, h_km, h_rad32, h_rad32inv; // h_km: K lowered for the mixed filter
+    std::vector<float> h_rec32, h_k, h_km, h_rad32, h_rad32inv; // h_km: -K' of the mixed filter (K lowered by its margin, negated)
     std::vector<int32_t> h_material;
     void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_spheres_m = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr; // _m: leaf records with the mixed mode's lowered K
     int32_t bvh_n_nodes = 0;
@@ -249,7 +249,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
     // throughput records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
     auto pair_slot = [](size_t i, int component) { return 8 * (i / 2) + 2 * component + (i % 2); };
-    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32k[pair_slot(i, 3)] = 3.402823466e+38f; rec32m[pair_slot(i, 3)] = 3.402823466e+38f; }
+    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32k[pair_slot(i, 3)] = 3.402823466e+38f; rec32m[pair_slot(i, 3)] = -3.402823466e+38f; }
     double reach = 0.0;
     bool filter_ok = true;
     std::vector<int32_t> smat(ns), mtype(nm);
@@ -263,11 +263,12 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         const double c2 = static_cast<double>(rec32[4 * i]) * rec32[4 * i] + static_cast<double>(rec32[4 * i + 1]) * rec32[4 * i + 1] + static_cast<double>(rec32[4 * i + 2]) * rec32[4 * i + 2];
         const double r2 = static_cast<double>(r) * r;
         rec32k[pair_slot(i, 3)] = static_cast<float>(c2 - r2);
-        // mixed mode: K lowered by the sphere's share of the filter margin, 2^-17 (|c|^2 + r^2), and rounded down
+        // mixed mode: the filter adds -K' to the square of c.e, K' = K lowered by the sphere's share of the filter
+        // margin, 2^-16 (|c|^2 + r^2); the record holds -K' rounded up (K' rounded down: the side that keeps more)
         {
-            const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 131072.0);
-            float km = static_cast<float>(lowered);
-            if (static_cast<double>(km) > lowered) km = std::nextafterf(km, -INFINITY);
+            const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 65536.0);
+            float km = static_cast<float>(-lowered);
+            if (static_cast<double>(km) < -lowered) km = std::nextafterf(km, INFINITY);
             for (int k = 0; k < 3; ++k) rec32m[pair_slot(i, k)] = rec32[4 * i + k];
             rec32m[pair_slot(i, 3)] = km;
             const double far = std::sqrt(c2) + std::fabs(static_cast<double>(r));
@@ -467,7 +468,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
         if (!bvh.spheres.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
         {
-            // the same leaf records with the mixed filter's lowered K (pad records of a leaf keep theirs)
+            // the same leaf records with the mixed filter's -K' in place of K
             std::vector<rtk::BvhSphere> lowered(bvh.spheres);
             for (rtk::BvhSphere &sp : lowered) if (sp.index >= 0 && sp.index < world->n_spheres) sp.k = world->h_km[static_cast<size_t>(sp.index)];
             HIP_TRY(hipMalloc(&world->bvh_spheres_m, std::max<size_t>(64, lowered.size() * sizeof(rtk::BvhSphere))));

@@ -606,20 +606,31 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             }
         };
         // the uncommon continuation for one sphere: some lane's line meets it
-        float behind = 0.0f; // mixed mode: h below -behind is certainly negative (set with the filter's per-ray values)
+        // mixed mode, per-ray values of the filter (set below): the origin's parameter on the filter's line, the lowered
+        // threshold, and the bound below which the centre's parameter relative to the origin is certainly negative
+        float s_o = 0.0f, thr_l = 0.0f, behind = 0.0f;
         skip_sphere = -1;
         auto park = [&](const auto h, const auto cc, const auto disc, const int i) {
             using T = decltype(disc);
-            // mixed mode: the filter's discriminant carries its error margin (see below), and a NaN keeps the sphere
-            const bool meets = MIXED ? !(disc < T(0)) : (disc >= T(0));
+            // mixed mode: `disc` is the filter's value w, which carries the error margin (see below); a sphere is kept
+            // unless w is below the threshold, and a NaN keeps it
+            bool meets;
+            if constexpr (MIXED) meets = !(disc < thr_l); else meets = (disc >= T(0));
             if (__builtin_amdgcn_ballot_w64(meets) != 0ull) {
                 // A line that meets the sphere only behind the origin (h <= 0) while the origin
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
                 // (the sphere the segment starts on was tested before the scan)
-                // Mixed mode: only when both signs are certain despite the f32 rounding.
+                // Mixed mode: only when both signs are certain despite the f32 rounding -- the centre's parameter
+                // relative to the origin, hs, is below -behind, and hs^2 exceeds the lowered discriminant w - thr, which
+                // makes c = hs^2 - disc of main.odin:248 positive (per unit direction).
                 // (plain & and | on the lane predicates: each is a compare into a scalar mask and the combination scalar
                 // logic, where && and || would branch around the second compare)
-                const bool ahead = MIXED ? !((h < T(-behind)) & ((cc > T(0)) | (i == skip_sphere))) : ((h > T(0)) | (cc < T(0)));
+                bool ahead;
+                if constexpr (MIXED) {
+                    (void)cc;
+                    const float hs = h - s_o, dl = disc - thr_l;
+                    ahead = !((hs < -behind) & ((fma_rn(hs, hs, -dl) > 0.0f) | (i == skip_sphere)));
+                } else ahead = (h > T(0)) | (cc < T(0));
                 const bool cand = meets & ahead & (!FMA | (i != start_sphere));
                 if constexpr (WQ) {
                     const unsigned long long cmask = __builtin_amdgcn_ballot_w64(cand);
@@ -661,29 +672,35 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             // discriminant is -inf.  `park` receives a*c where the literal modes pass c: only its
             // sign is used there, and a > 0.
             //
-            // Mixed mode runs the same instructions on the f64 ray rounded to f32, as a filter that must
-            // never drop a sphere the f64 test of main.odin:245-261 would report as hit.  With
-            // u = 2^-24, S = |centre| + |o| + r and everything exact but the f32 roundings, the
-            // computed discriminant differs from the f64 one by at most 34 u a S^2: 8 from rounding
-            // d, o, centre and r to f32 (gradient of h^2 - a*c times the input errors), 12 from h
-            // (three fused roundings and the plain dot product d.o, doubled by squaring), 12 from
-            // a*c (K, the roundings of a, a*(-2o), a*|o|^2 and of the four fused operations), 2 from
-            // the last fused operation.  S^2 <= 3(|centre|^2 + r^2 + |o|^2), so lowering a*c by
-            // 2^-17 a (|centre|^2 + r^2 + |o|^2) = 42.7 u a S^2 covers it; that margin costs no
-            // instruction: the per-sphere part is folded into the record's K on the host, the
-            // per-ray part into a*|o|^2 here.  A sphere is kept when the lowered discriminant is not
-            // negative.  The bound needs every product to stay a normal f32 number: the world is
-            // checked for that on the host (2^-20 <= r, |centre| + r <= 2^20) and a ray outside
-            // 2^-40 <= a <= 2^40, |o|^2 <= 2^40 (or not a number) keeps every sphere.
-            float d_o, o_o, fa;
+            // Mixed mode: a filter on the f64 ray rounded to f32 that must never drop a sphere the f64 test of
+            // main.odin:245-261 would report as hit, in seven fused operations per sphere.  The ray becomes a unit
+            // direction e and the foot point f of the coordinate origin on its line (f.e = 0); then
+            //     r^2 - dist(centre, line)^2 = (c.e)^2 - K + 2 c.f - |f|^2          (= disc / a of main.odin:249),
+            //     h = c.e (3 operations),  w = fma(cz, 2fz, fma(cy, 2fy, fma(cx, 2fx, fma(h, h, -K)))) (4),
+            // and the sphere is kept unless w < |f|^2.  With u = 2^-24, S = |centre| + |o| + r and everything exact but
+            // the f32 roundings, w - |f|^2 differs from the f64 value by at most 43 u S^2: 18 from rounding d, o, centre
+            // and r to f32 and from the roundings of e and f (the line moves by at most 8 u S near a sphere it
+            // meets), 10 because |e|^2 - 1 and f.e are not exactly zero (9 u and 13 u |o|), 10 from evaluating h and
+            // w, 4 from |f|^2, 1 from the difference.  S^2 <= 3(|centre|^2 + r^2 + |o|^2), so lowering K and |f|^2 by
+            // 2^-16 (|centre|^2 + r^2) and 2^-16 |o|^2 = 85 u S^2 in all covers it with 42 u S^2 to spare; the margin
+            // costs no instruction per sphere: the sphere's share is in its record (which holds -K', rounded up), the
+            // ray's share in the threshold.  The spare part makes a second decision certain: hs = h - o.e is the centre's
+            // parameter relative to the origin, off by at most 12 u S, so hs < -behind = -2^-19 (reach + |o|_1) is
+            // certainly negative, and hs^2 > w - thr then means c = hs^2 - disc/a of main.odin:248 is positive (24 u S^2
+            // for the error of hs^2): the line meets the sphere only behind an origin outside it.  The bound needs
+            // every product to stay a normal f32 number: the world is checked for that on the host
+            // (2^-20 <= r, |centre| + r <= 2^20) and a ray outside 2^-40 <= |d|^2 <= 2^40, |o|^2 <= 2^40 (or not a number)
+            // keeps every sphere.  Division and square root are IEEE, so the CPU restatement forms the same values.
+            float d_o = 0.0f, o_o, fa;
             V3<float> fd, fo;
+            V3<float> fe = {0.0f, 0.0f, 0.0f}, f2 = {0.0f, 0.0f, 0.0f}; // mixed mode: unit direction, twice the foot point
             if constexpr (FMA) { fd = rd; fo = ro; fa = a; }
             else {
                 fd = {static_cast<float>(rd.x), static_cast<float>(rd.y), static_cast<float>(rd.z)};
                 fo = {static_cast<float>(ro.x), static_cast<float>(ro.y), static_cast<float>(ro.z)};
                 fa = dot(fd, fd);
             }
-            d_o = dot(fd, fo); o_o = dot(fo, fo);
+            o_o = dot(fo, fo);
             // The sphere this segment starts on: its origin is the previous hit point, so c is zero
             // up to the rounding of that point.  The reference's f64 arithmetic sees |c| ~ 1e-15
             // and its near root falls below t_min; in f32 the rounding of c is large enough to give
@@ -692,6 +709,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             // a hit, for h > 0 (a segment through the inside).  It is tested first and left out
             // of the scan.
             if constexpr (FMA) {
+            d_o = dot(fd, fo);
             if (start_sphere >= 0) {
                 const float ocx = start_center.x - ro.x, ocy = start_center.y - ro.y, ocz = start_center.z - ro.z;
                 const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a; // (d.oc)/a as in `resolve`
@@ -699,25 +717,30 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
             }
-            float aox = fa * (-2.0f * fo.x), aoy = fa * (-2.0f * fo.y), aoz = fa * (-2.0f * fo.z), aoo = fa * o_o;
+            float aox = 0.0f, aoy = 0.0f, aoz = 0.0f, aoo = 0.0f;
+            if constexpr (FMA) { aox = fa * (-2.0f * fo.x); aoy = fa * (-2.0f * fo.y); aoz = fa * (-2.0f * fo.z); aoo = fa * o_o; }
             if constexpr (MIXED) {
-                aoo = aoo * (1.0f - 7.62939453125e-06f); // the ray's share of the margin: 2^-17 a |o|^2
-                // h < -behind is certainly negative: h is off by at most 8 u |d| S, S <= reach + |o|, and the sums of
-                // absolute components bound the lengths from above
+                const float nd = sqrt_rn(fa), inv_nd = 1.0f / nd;
+                fe = fd * inv_nd;
+                s_o = dot(fo, fe);
+                const V3<float> ft = {fma_rn(-s_o, fe.x, fo.x), fma_rn(-s_o, fe.y, fo.y), fma_rn(-s_o, fe.z, fo.z)};
+                thr_l = fma_rn(-1.52587890625e-05f, o_o, dot(ft, ft)); // |f|^2 lowered by the ray's share of the margin, 2^-16 |o|^2
+                f2 = {ft.x + ft.x, ft.y + ft.y, ft.z + ft.z};
                 reach_o = P.filter_reach + (abs_rn(fo.x) + abs_rn(fo.y) + abs_rn(fo.z));
-                behind = 9.5367431640625e-07f * (abs_rn(fd.x) + abs_rn(fd.y) + abs_rn(fd.z)) * reach_o; // 2^-20 = 16 u
+                behind = 1.9073486328125e-06f * reach_o; // 2^-19 = 32 u
                 // The sphere this segment starts on.  Its origin p = o' + t d' was a root of that sphere's equation,
                 // so c = |centre - p|^2 - r^2 (main.odin:248) is zero up to rounding: |c| <= 64 * 2^-53 (reach + |o'|)^2
-                // (21 from the root and the hit point, 4 from evaluating c; o' the previous origin).  With h
-                // certainly below -behind/2 the roots of main.odin:253-257 are <= 0 (c >= 0) or the far one is
-                // c/(h - sqrt(disc)) <= |c| / (2|h|) <= |c| / behind; below t_min the sphere cannot be hit and
+                // (21 from the root and the hit point, 4 from evaluating c; o' the previous origin).  With the
+                // centre's parameter certainly below -behind/2 per unit direction, h of main.odin:247 is below
+                // -|d| behind/2, and the roots of main.odin:253-257 are <= 0 (c >= 0) or the far one is
+                // c/(h - sqrt(disc)) <= |c| / (2|h|) <= |c| / (|d| behind); below t_min the sphere cannot be hit and
                 // ray_sphere_intersection need not be evaluated for it.
-                skip_sphere = (start_sphere >= 0 && start_cc_bound < 9.0e-4f * behind) ? start_sphere : -1;
+                skip_sphere = (start_sphere >= 0 && start_cc_bound < 9.0e-4f * (nd * behind)) ? start_sphere : -1;
                 const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f); // 2^-40, 2^40
                 if (!in_range) {
-                    // every sphere is a candidate of this ray: h = 0, a*c = -1, discriminant 1
-                    fd = {0.0f, 0.0f, 0.0f}; d_o = 0.0f; fa = 0.0f;
-                    aox = 0.0f; aoy = 0.0f; aoz = 0.0f; aoo = -1.0f;
+                    // every sphere is a candidate of this ray: h = 0, w = -K', threshold the lowest number
+                    fe = {0.0f, 0.0f, 0.0f}; f2 = {0.0f, 0.0f, 0.0f}; s_o = 0.0f;
+                    thr_l = -Lim<float>::max_v;
                     behind = Lim<float>::max_v;
                     skip_sphere = -1;
                     reach_o = Lim<float>::max_v;
@@ -737,17 +760,16 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 float closest_up = Lim<float>::max_v; // mixed mode: `closest` rounded up to f32, for the box tests
                 auto test_sphere = [&](const float cx, const float cy, const float cz, const float K, const float r2, const int index) {
                     ++bvh_tests;
-                    // stage 1: the list scan's filter
-                    const float h = fma_rn(cz, fd.z, fma_rn(cy, fd.y, fma_rn(cx, fd.x, -d_o)));
-                    const float m = fma_rn(K, fa, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
-                    const float disc = fma_rn(h, h, -m);
                     if constexpr (MIXED) {
-                        // the conservative form (K carries the sphere's share of the margin, aoo the ray's), then
+                        // the list scan's conservative filter (the record holds -K' in place of K), then
                         // ray_sphere_intersection as written (main.odin:245-261) in f64 and the caller's strict `<`
                         // (:542-545); equal roots go to the lower list index, which the list reaches first
                         (void)r2;
-                        if (disc < 0.0f) return; // a NaN keeps the sphere
-                        if ((h < -behind) && ((m > 0.0f) || (index == skip_sphere))) return;
+                        const float h = fma_rn(cz, fe.z, fma_rn(cy, fe.y, cx * fe.x));
+                        const float w = fma_rn(cz, f2.z, fma_rn(cy, f2.y, fma_rn(cx, f2.x, fma_rn(h, h, K))));
+                        if (w < thr_l) return; // a NaN keeps the sphere
+                        const float hs = h - s_o;
+                        if ((hs < -behind) && ((fma_rn(hs, hs, -(w - thr_l)) > 0.0f) || (index == skip_sphere))) return;
 #ifdef RT_DIAG_COUNTERS
                         if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_parked; // one lane per execution by the wave (stats[7]; 5 and 6 hold the hierarchy's counts)
 #endif
@@ -766,6 +788,10 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                             closest_up = __double2float_ru(root);
                         }
                     } else {
+                    // stage 1: the list scan's filter
+                    const float h = fma_rn(cz, fd.z, fma_rn(cy, fd.y, fma_rn(cx, fd.x, -d_o)));
+                    const float m = fma_rn(K, fa, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
+                    const float disc = fma_rn(h, h, -m);
                     if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) return;
                     // stage 2: the roots of `resolve`
                     const float ocx = cx - ro.x, ocy = cy - ro.y, ocz = cz - ro.z;
@@ -868,21 +894,34 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     }
                 }
             } else {
-            const F2 dx2 = {fd.x, fd.x}, dy2 = {fd.y, fd.y}, dz2 = {fd.z, fd.z}, nd_o2 = {-d_o, -d_o};
-            const F2 ox2 = {aox, aox}, oy2 = {aoy, aoy}, oz2 = {aoz, aoz}, oo2 = {aoo, aoo}, a2 = {fa, fa};
+            // per-ray factors, both halves alike: throughput mode d, -d.o, a(-2o), a|o|^2, a; mixed mode e and 2f
+            const F2 dx2 = MIXED ? F2{fe.x, fe.x} : F2{fd.x, fd.x}, dy2 = MIXED ? F2{fe.y, fe.y} : F2{fd.y, fd.y}, dz2 = MIXED ? F2{fe.z, fe.z} : F2{fd.z, fd.z};
+            const F2 ox2 = MIXED ? F2{f2.x, f2.x} : F2{aox, aox}, oy2 = MIXED ? F2{f2.y, f2.y} : F2{aoy, aoy}, oz2 = MIXED ? F2{f2.z, f2.z} : F2{aoz, aoz};
+            const F2 nd_o2 = {-d_o, -d_o}, oo2 = {aoo, aoo}, a2 = {fa, fa};
+            const float gate_at = MIXED ? thr_l : 0.0f;
             auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
-                const F2 hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
-                const F2 hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
-                const F2 mp = fma2(p.k, a2, fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))));
-                const F2 mq = fma2(q.k, a2, fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))));
-                const F2 dp = fma2(hp, hp, -mp);
-                const F2 dq = fma2(hq, hq, -mq);
+                F2 hp, hq, mp, mq, dp, dq;
+                if constexpr (MIXED) {
+                    // h = c.e, w = (h*h - K') + 2 c.f: seven packed operations per pair of spheres (p.k holds -K')
+                    hp = fma2(p.cz, dz2, fma2(p.cy, dy2, p.cx * dx2));
+                    hq = fma2(q.cz, dz2, fma2(q.cy, dy2, q.cx * dx2));
+                    dp = fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, fma2(hp, hp, p.k))));
+                    dq = fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, fma2(hq, hq, q.k))));
+                    mp = dp; mq = dq; // not used by `park` in this mode
+                } else {
+                    hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
+                    hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
+                    mp = fma2(p.k, a2, fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))));
+                    mq = fma2(q.k, a2, fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))));
+                    dp = fma2(hp, hp, -mp);
+                    dq = fma2(hq, hq, -mq);
+                }
                 const float dmax = max_num(max_num(dp.x, dp.y), max_num(dq.x, dq.y));
 #ifdef RT_DIAG_NO_PARK
                 asm volatile("" :: "v"(dmax));
                 if (false) {
 #else
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= 0.0f) != 0ull, 0)) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= gate_at) != 0ull, 0)) {
 #endif
                     RT_DIAG_COUNT(diag_entries);
 #ifdef RT_DIAG_PHASES

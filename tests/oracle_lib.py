@@ -60,12 +60,14 @@ class Oracle:
 
     def mixed_filter(self, o, d, c, radius, reach, start_cc_bound=-1.0):
         """the f32 candidate filter of RT_PRECISION_MIXED for one ray and one sphere ->
-        dict(disc, m, h, behind, in_range, kept, next_cc_bound); start_cc_bound >= 0: the segment starts on this
-        sphere and |c| of main.odin:248 is known to be at most that"""
+        dict(disc, m, h, behind, in_range, kept, next_cc_bound, nd), per unit direction: disc = the lowered
+        discriminant w - thr, h = the centre's parameter relative to the origin, m = h^2 - disc (stands for c of
+        main.odin:248), nd = |d|; start_cc_bound >= 0: the segment starts on this sphere and |c| of main.odin:248 is
+        known to be at most that"""
         o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))
-        out = np.zeros(7, dtype=np.float64)
+        out = np.zeros(8, dtype=np.float64)
         self.L.oracle_mixed_filter(o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, reach, start_cc_bound, out.ctypes.data)
-        return dict(disc=out[0], m=out[1], h=out[2], behind=out[3], in_range=bool(out[4]), kept=bool(out[5]), next_cc_bound=out[6])
+        return dict(disc=out[0], m=out[1], h=out[2], behind=out[3], in_range=bool(out[4]), kept=bool(out[5]), next_cc_bound=out[6], nd=out[7])
 
     def material_scatter(self, precision, material, ray_o, ray_d, hit_p, hit_n, front_face, seed, pixel, sample, bounce):
         m = np.zeros(1, dtype=rt.MATERIAL_DTYPE)

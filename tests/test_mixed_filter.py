@@ -55,7 +55,7 @@ def cases(rng, n):
 
 def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
     rng = np.random.default_rng(2024)
-    worst_low, worst_high, kept, total = None, None, 0, 0
+    worst_low, worst_high, worst_h, kept, total = None, None, 0.0, 0, 0
     for o, d, c, r in cases(rng, 6000):
         cf = np.float32(c).astype(np.float64)
         reach = float(np.linalg.norm(cf) + abs(np.float32(r))) * 1.000001
@@ -67,22 +67,30 @@ def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
         total += 1
         kept += f["kept"]
         S = norm_upper(c) + norm_upper(o) + abs(Fraction(float(r)))
-        unit = U * a * S * S
-        lowered = Fraction(f["disc"])
-        # the lowered f32 discriminant is never below the exact one: the margin (>= 42.7 u a S^2 / 3 ...) exceeds the rounding (<= 34 u a S^2)
-        assert lowered >= disc, (o, d, c, r)
-        gap = (lowered - disc) / unit
+        unit = U * S * S
+        # the filter works per unit direction: its lowered discriminant w - thr stands for disc / a = r^2 - dist(centre, line)^2
+        lowered, exact = Fraction(f["disc"]), disc / a
+        # never below the exact one, and by at least the 24 u S^2 the behind-the-origin rule relies on:
+        # the margin (>= 85 u S^2) exceeds the rounding (<= 43 u S^2) by more than that
+        assert lowered >= exact + 24 * unit, (o, d, c, r)
+        gap = (lowered - exact) / unit
         worst_low = gap if worst_low is None else min(worst_low, gap)
         worst_high = gap if worst_high is None else max(worst_high, gap)
         if disc >= 0:
             assert f["disc"] >= 0
+        # the centre's parameter relative to the origin, per unit direction: off by at most 12 u S
+        h_unit = float(h) / float(np.sqrt(float(a)))
+        err_h = abs(f["h"] - h_unit) / float(U * S)
+        assert err_h <= 12.0, (o, d, c, r)
+        worst_h = max(worst_h, err_h)
         # the behind-the-origin rule only fires when the exact signs agree
         if f["h"] < -f["behind"] and f["m"] > 0:
             assert h < 0 and cc > 0
         if disc >= 0 and not (h < 0 and cc > 0):
             assert f["kept"]
-    print(f"lowered - exact discriminant in units of u*a*S^2: min {float(worst_low):.2f}, max {float(worst_high):.2f}; kept {kept} of {total}")
-    assert worst_low > 0
+    print(f"lowered - exact discriminant (per unit direction) in units of u*S^2: min {float(worst_low):.2f}, max {float(worst_high):.2f}; "
+          f"error of the centre's parameter: at most {worst_h:.2f} u*S; kept {kept} of {total}")
+    assert worst_low > 24
 
 
 def test_start_sphere_rule_only_drops_what_the_reference_misses(oracle):
