@@ -208,24 +208,14 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
     return t;
 }
 
-/* The ray/sphere test of the GPU throughput arithmetic (f32), in two stages.
+/* Throughput arithmetic (RT_PRECISION_F32): the ray/sphere test in two stages.
  *
- * Stage 1, every sphere: the discriminant of main.odin:245-249 with the squares expanded so that
- * both h and a*c are dot products of a per-sphere vector with a per-ray vector:
- *     h   = d.(center - o)            = d.center - d.o
- *     a*c = a(|center - o|^2 - r^2)   = a(|center|^2 - r^2) - 2a center.o + a|o|^2
- * Per sphere: K = |center|^2 - r^2 (formed in f64 from the f32 centre and radius, rounded to
- * f32).  Per segment: a = d.d, d_o = d.o, o_o = o.o (plain left-to-right dot products), then
- * aox = a*(-2*ox) (likewise y, z) and aoo = a*o_o, each one rounded product.  Then, with fused
- * multiply-adds in exactly this order,
- *     h    = fma(cz, dz, fma(cy, dy, fma(cx, dx, -d_o)))
- *     m    = fma(K, a, fma(cz, aoz, fma(cy, aoy, fma(cx, aox, aoo))))        ( = a*c )
- *     disc = fma(h, h, -m)
- * A sphere is a candidate when disc >= 0, unless h <= 0 and m >= 0 (the line meets it only
- * behind an origin that lies outside it: both roots <= 0).  disc is the difference of two
- * numbers of size a*|center - o|^2, so it selects candidates and nothing more.
+ * Stage 1, every sphere: the conservative filter below (mixed_filter) on the f32 ray.  It drops a
+ * sphere only when its discriminant is negative by more than every rounding error, or when the
+ * line certainly meets it only behind an origin certainly outside it, so what stage 2 decides
+ * for the spheres it keeps is all that reaches the image.
  *
- * Stage 2, candidates only: the roots from the vector l that runs from the centre to the
+ * Stage 2, kept spheres only: the roots from the vector l that runs from the centre to the
  * line's closest point, whose length is of the size of the radius, so that the rounding error
  * scales with the sphere and not with its distance:
  *     oc = center - o,   q = fma(ocz, dz, fma(ocy, dy, ocx*dx)) * (1/a),
@@ -233,47 +223,19 @@ inline Real ray_sphere_intersection(const ray_t<Real> &r, vec3<Real> c, Real rad
  *     roots q -+ sqrt(D * (1/a)),
  * which is main.odin:249-258 with disc = a*D; the range tests and the order of the two roots
  * (main.odin:250-261) are unchanged.  r*r is the f32 product of the f32 radius. */
-struct expanded_ray { float dx, dy, dz, d_o, aox, aoy, aoz, aoo, a, inv_a; vec3<float> o; };
+struct expanded_ray { float dx, dy, dz, a, inv_a; vec3<float> o; };
 inline expanded_ray expand_ray(const ray_t<float> &r) {
     expanded_ray e;
     e.dx = r.direction.x; e.dy = r.direction.y; e.dz = r.direction.z;
-    e.d_o = dot(r.direction, r.origin);
-    const float o_o = dot(r.origin, r.origin);
     e.a = dot(r.direction, r.direction);
-    e.aox = e.a * (-2.0f * r.origin.x); e.aoy = e.a * (-2.0f * r.origin.y); e.aoz = e.a * (-2.0f * r.origin.z);
-    e.aoo = e.a * o_o;
     e.inv_a = 1.0f / e.a; /* one reciprocal per segment instead of a division per root */
     e.o = r.origin;
     return e;
 }
-inline float sphere_constant(float cx, float cy, float cz, float radius) {
-    return static_cast<float>(static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz - static_cast<double>(radius) * radius);
-}
-inline float ray_sphere_intersection_expanded(const expanded_ray &e, vec3<float> c, float K, float radius, float t_min, float t_max) {
-    /* stage 1 */
-    const float h = std::fmaf(c.z, e.dz, std::fmaf(c.y, e.dy, std::fmaf(c.x, e.dx, -e.d_o)));
-    const float m = std::fmaf(K, e.a, std::fmaf(c.z, e.aoz, std::fmaf(c.y, e.aoy, std::fmaf(c.x, e.aox, e.aoo))));
-    const float disc = std::fmaf(h, h, -m);
-    if (!(disc >= 0)) return t_max;
-    if (!(h > 0 || m < 0)) return t_max;
-    /* stage 2 */
-    const float ocx = c.x - e.o.x, ocy = c.y - e.o.y, ocz = c.z - e.o.z;
-    const float q = std::fmaf(ocz, e.dz, std::fmaf(ocy, e.dy, ocx * e.dx)) * e.inv_a;
-    const float lx = std::fmaf(-q, e.dx, ocx), ly = std::fmaf(-q, e.dy, ocy), lz = std::fmaf(-q, e.dz, ocz);
-    const float D = radius * radius - std::fmaf(lz, lz, std::fmaf(ly, ly, lx * lx));
-    if (!(D >= 0)) return t_max;
-    const float s = std::sqrt(D * e.inv_a);
-    float root = q - s;
-    if (root < t_min || t_max <= root) {
-        root = q + s;
-        if (root < t_min || t_max <= root) return t_max;
-    }
-    return root;
-}
-
-/* The candidate filter of the GPU mixed mode: seven fused f32 operations per sphere on the f64 ray
- * rounded to f32, with an error margin, so that no sphere the f64 test of main.odin:245-261 reports
- * as hit is ever dropped.  The ray is taken as a unit direction e = d/|d| and the foot point
+/* The candidate filter of the GPU throughput and mixed modes: seven fused f32 operations per sphere on the
+ * f32 ray (mixed mode: the f64 ray rounded to f32), with an error margin, so that no sphere whose exact
+ * discriminant (main.odin:249) is non-negative -- in particular none the f64 test of main.odin:245-261
+ * reports as hit -- is ever dropped.  The ray is taken as a unit direction e = d/|d| and the foot point
  * f = o - (o.e) e of the coordinate origin on its line; then
  *     r^2 - dist(center, line)^2 = (c.e)^2 - K + 2 c.f - |f|^2,   K = |center|^2 - r^2
  * (= disc / a of main.odin:249), evaluated as
@@ -321,7 +283,7 @@ inline filter_ray make_filter_ray(const ray_t<double> &r, float reach) {
     f.f2 = {ft.x + ft.x, ft.y + ft.y, ft.z + ft.z};
     f.reach_o = reach + (std::fabs(fo.x) + std::fabs(fo.y) + std::fabs(fo.z));
     f.behind = 1.9073486328125e-06f * f.reach_o;
-    f.in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f);
+    f.in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f) && (reach <= 1048576.0f);
     if (!f.in_range) f.reach_o = FLT_MAX;
     return f;
 }
@@ -339,6 +301,24 @@ inline bool mixed_filter(const filter_ray &f, vec3<float> c, float Kn, bool on_s
     const float hs = h - f.s_o;
     if (hs < -f.behind && (std::fmaf(hs, hs, -(w - f.thr)) > 0 || on_start)) return false;
     return true;
+}
+
+inline float ray_sphere_intersection_expanded(const expanded_ray &e, const filter_ray &f, vec3<float> c, float Kn, float radius, float t_min, float t_max) {
+    /* stage 1 */
+    if (!mixed_filter(f, c, Kn)) return t_max;
+    /* stage 2 */
+    const float ocx = c.x - e.o.x, ocy = c.y - e.o.y, ocz = c.z - e.o.z;
+    const float q = std::fmaf(ocz, e.dz, std::fmaf(ocy, e.dy, ocx * e.dx)) * e.inv_a;
+    const float lx = std::fmaf(-q, e.dx, ocx), ly = std::fmaf(-q, e.dy, ocy), lz = std::fmaf(-q, e.dz, ocz);
+    const float D = radius * radius - std::fmaf(lz, lz, std::fmaf(ly, ly, lx * lx));
+    if (!(D >= 0)) return t_max;
+    const float s = std::sqrt(D * e.inv_a);
+    float root = q - s;
+    if (root < t_min || t_max <= root) {
+        root = q + s;
+        if (root < t_min || t_max <= root) return t_max;
+    }
+    return root;
 }
 
 /* Throughput arithmetic, the sphere a scattered segment starts on.  Its origin is the hit point of
@@ -467,8 +447,8 @@ template <class Real> inline vec3<Real> background_color(const ray_t<Real> &r) {
 }
 
 /* ---------------------------------------------------------------- the world in Real */
-template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float K, inv_radius; /* |center|^2 - r^2 and 1/r: throughput arithmetic only */
-                                        vec3<float> center32; float Km; /* mixed mode's filter record: f32 center and -K' */ };
+template <class Real> struct sphere_t { vec3<Real> center; Real radius; int64_t material_index; float inv_radius; /* 1/r: throughput arithmetic only */
+                                        vec3<float> center32; float Km; /* the filter's record: f32 center and -K' */ };
 template <class Real> struct camera_t {
     vec3<Real> position, du, dv, top_left, dof_u, dof_v;
     Real dof_angle;
@@ -488,7 +468,7 @@ template <class Real> struct scene_t {
         for (int64_t i = 0; i < ns; ++i) {
             const float cx = static_cast<float>(s[i].center.x), cy = static_cast<float>(s[i].center.y), cz = static_cast<float>(s[i].center.z), rf = static_cast<float>(s[i].radius);
             spheres[i] = {cvt<Real>(s[i].center), static_cast<Real>(s[i].radius), s[i].material_index,
-                          sphere_constant(cx, cy, cz, rf), 1.0f / rf, {cx, cy, cz}, sphere_constant_lowered(cx, cy, cz, rf)};
+                          1.0f / rf, {cx, cy, cz}, sphere_constant_lowered(cx, cy, cz, rf)};
             const double far = std::sqrt(static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz) + std::fabs(static_cast<double>(rf));
             reach = std::max(reach, far);
             if (!(std::fabs(static_cast<double>(rf)) >= 1.0 / 1048576.0) || !(far <= 1048576.0)) filter_ok = false;
@@ -533,13 +513,15 @@ inline vec3<Real> trace_sample(const scene_t<Real> &sc, seed_keys keys, int64_t 
         const Real SHADOW_ACNE_RAY_OFFSET = Real(0.001);
         if constexpr (FMA) {
             const expanded_ray e = expand_ray(ray);
+            const filter_ray f = make_filter_ray(ray_t<double>{{ray.origin.x, ray.origin.y, ray.origin.z}, {ray.direction.x, ray.direction.y, ray.direction.z}},
+                                                 sc.filter_ok ? sc.filter_reach : FLT_MAX);
             if (start_sphere >= 0) {
                 Real t = ray_sphere_intersection_from_surface(e, sc.spheres[start_sphere].center, SHADOW_ACNE_RAY_OFFSET, closest_t);
                 if (t < closest_t) { closest_t = t; hit_index = start_sphere; }
             }
             for (int64_t i = 0; i < n; ++i) {
                 if (i == start_sphere) continue;
-                Real t = ray_sphere_intersection_expanded(e, sc.spheres[i].center, sc.spheres[i].K, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
+                Real t = ray_sphere_intersection_expanded(e, f, sc.spheres[i].center32, sc.spheres[i].Km, sc.spheres[i].radius, SHADOW_ACNE_RAY_OFFSET, closest_t);
                 if (t < closest_t) { closest_t = t; hit_index = i; }
             }
         } else if constexpr (MIXED) {
@@ -756,8 +738,15 @@ double oracle_ray_sphere_intersection(int32_t precision, const double *o, const 
     }
     ray_t<float> r{{(float)o[0], (float)o[1], (float)o[2]}, {(float)d[0], (float)d[1], (float)d[2]}};
     vec3<float> cf{(float)c[0], (float)c[1], (float)c[2]};
-    if (precision == RT_PRECISION_F32)
-        return ray_sphere_intersection_expanded(expand_ray(r), cf, sphere_constant(cf.x, cf.y, cf.z, (float)radius), (float)radius, (float)t_min, (float)t_max);
+    if (precision == RT_PRECISION_F32) {
+        /* the filter's reach for a world of this one sphere */
+        const double far = std::sqrt((double)cf.x * cf.x + (double)cf.y * cf.y + (double)cf.z * cf.z) + std::fabs((double)(float)radius);
+        const bool ok = std::fabs((double)(float)radius) >= 1.0 / 1048576.0 && far <= 1048576.0;
+        float reach = static_cast<float>(far);
+        if (static_cast<double>(reach) < far) reach = std::nextafterf(reach, INFINITY);
+        const filter_ray f = make_filter_ray(ray_t<double>{{r.origin.x, r.origin.y, r.origin.z}, {r.direction.x, r.direction.y, r.direction.z}}, ok ? reach : FLT_MAX);
+        return ray_sphere_intersection_expanded(expand_ray(r), f, cf, sphere_constant_lowered(cf.x, cf.y, cf.z, (float)radius), (float)radius, (float)t_min, (float)t_max);
+    }
     return ray_sphere_intersection<float>(r, cf, (float)radius, (float)t_min, (float)t_max);
 }
 

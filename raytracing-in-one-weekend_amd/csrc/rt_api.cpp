@@ -98,8 +98,7 @@ struct rt_world_s {
     uint64_t n_calls = 0;
     int last_slot = -1;
     void *rec32 = nullptr, *rec64 = nullptr;   // {cx, cy, cz, r*r}
-    void *rec32k = nullptr;                     // {cx, cy, cz, |c|^2 - r*r}: the throughput kernel's records
-    void *rec32m = nullptr;                     // the same pairs with -K' in place of K, K' lowered by the mixed mode's filter margin
+    void *rec32m = nullptr;                     // the filter's records, per pair of spheres {cx0,cx1, cy0,cy1, cz0,cz1, -K'0,-K'1}: K = |c|^2 - r*r lowered by the filter margin
     float filter_reach = 0.0f;                  // max |c| + |r| over the spheres, rounded up
     bool filter_ok = true;                      // every sphere inside the range the filter's error bound needs
     void *rad32 = nullptr, *rad64 = nullptr;
@@ -108,9 +107,9 @@ struct rt_world_s {
     void *mat32 = nullptr, *mat64 = nullptr;   // {albedo, param1}
     int32_t *material_type = nullptr;
     // RT_FETCH_BVH: built and uploaded on first use from the host copies kept here
-    std::vector<float> h_rec32, h_k, h_km, h_rad32, h_rad32inv; // h_km: -K' of the mixed filter (K lowered by its margin, negated)
+    std::vector<float> h_rec32, h_km, h_rad32, h_rad32inv; // h_km: -K' of the filter (K lowered by its margin, negated)
     std::vector<int32_t> h_material;
-    void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_spheres_m = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr; // _m: leaf records with the mixed mode's lowered K
+    void *bvh_nodes = nullptr, *bvh_spheres = nullptr, *bvh_lds_boxes = nullptr, *bvh_lds_links = nullptr;
     int32_t bvh_n_nodes = 0;
     bool bvh_built = false;
     rtk::BvhHost bvh_host;                      // grid and big-sphere list (node and sphere vectors are released after upload)
@@ -245,11 +244,11 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     // record has r*r = -inf, which makes its discriminant -inf (or NaN): never a candidate
     const size_t ns_pad = (ns + rtk::SCAN_STEP - 1) / rtk::SCAN_STEP * rtk::SCAN_STEP;
     const size_t ns_alloc = ns_pad + rtk::GROUP;
-    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32k(4 * ns_alloc, 0.0f), rec32m(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
+    std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32m(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
     // throughput records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
     auto pair_slot = [](size_t i, int component) { return 8 * (i / 2) + 2 * component + (i % 2); };
-    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32k[pair_slot(i, 3)] = 3.402823466e+38f; rec32m[pair_slot(i, 3)] = -3.402823466e+38f; }
+    for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32m[pair_slot(i, 3)] = -3.402823466e+38f; }
     double reach = 0.0;
     bool filter_ok = true;
     std::vector<int32_t> smat(ns), mtype(nm);
@@ -258,12 +257,10 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         const float r = static_cast<float>(s.radius);
         rec32[4 * i + 0] = static_cast<float>(s.center.x); rec32[4 * i + 1] = static_cast<float>(s.center.y);
         rec32[4 * i + 2] = static_cast<float>(s.center.z); rec32[4 * i + 3] = r * r; // sphere_radius*sphere_radius, main.odin:248
-        for (int k = 0; k < 3; ++k) rec32k[pair_slot(i, k)] = rec32[4 * i + k];
-        // K = |centre|^2 - r^2 of the f32 centre and radius, formed in f64 and rounded once
+        // K = |centre|^2 - r^2 of the f32 centre and radius, formed in f64
         const double c2 = static_cast<double>(rec32[4 * i]) * rec32[4 * i] + static_cast<double>(rec32[4 * i + 1]) * rec32[4 * i + 1] + static_cast<double>(rec32[4 * i + 2]) * rec32[4 * i + 2];
         const double r2 = static_cast<double>(r) * r;
-        rec32k[pair_slot(i, 3)] = static_cast<float>(c2 - r2);
-        // mixed mode: the filter adds -K' to the square of c.e, K' = K lowered by the sphere's share of the filter
+        // the filter (throughput and mixed mode) adds -K' to the square of c.e, K' = K lowered by the sphere's share of the filter
         // margin, 2^-16 (|c|^2 + r^2); the record holds -K' rounded up (K' rounded down: the side that keeps more)
         {
             const double lowered = (c2 - r2) - (c2 + r2) * (1.0 / 65536.0);
@@ -288,9 +285,8 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     }
     rt_world *w = new rt_world_s();
     w->h_rec32.assign(rec32.begin(), rec32.begin() + 4 * ns);
-    w->h_k.resize(ns);
     w->h_km.resize(ns);
-    for (size_t i = 0; i < ns; ++i) { w->h_k[i] = rec32k[pair_slot(i, 3)]; w->h_km[i] = rec32m[pair_slot(i, 3)]; }
+    for (size_t i = 0; i < ns; ++i) w->h_km[i] = rec32m[pair_slot(i, 3)];
     w->h_rad32 = rad32; w->h_rad32inv = rad32inv; w->h_material = smat;
     w->filter_ok = filter_ok;
     w->filter_reach = static_cast<float>(reach);
@@ -307,7 +303,6 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload(&w->rec32, rec32.data(), rec32.size() * 4);
-    if (e == hipSuccess) e = upload(&w->rec32k, rec32k.data(), rec32k.size() * 4);
     if (e == hipSuccess) e = upload(&w->rec32m, rec32m.data(), rec32m.size() * 4);
     if (e == hipSuccess) e = upload(&w->rec64, rec64.data(), rec64.size() * 8);
     if (e == hipSuccess) e = upload(&w->rad32, rad32.data(), rad32.size() * 4);
@@ -346,7 +341,7 @@ int32_t rt_world_destroy(rt_world *w) {
     (void)guard.enter(w->device);
     // calls still in flight read the buffers freed below
     for (CallSlot &c : w->slots) if (c.used && c.ev_end) (void)hipEventSynchronize(c.ev_end);
-    void *bufs[] = {w->rec32, w->rec32k, w->rec32m, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue_ring, w->bvh_nodes, w->bvh_spheres, w->bvh_spheres_m, w->bvh_lds_boxes, w->bvh_lds_links};
+    void *bufs[] = {w->rec32, w->rec32m, w->rec64, w->rad32, w->rad32inv, w->rad64, w->sphere_material, w->mat32, w->mat64, w->material_type, w->slabs, w->queue_ring, w->bvh_nodes, w->bvh_spheres, w->bvh_lds_boxes, w->bvh_lds_links};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (CallSlot &c : w->slots) {
         if (c.ev_begin) (void)hipEventDestroy(c.ev_begin);
@@ -459,21 +454,14 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     if (fetch == RT_FETCH_BVH && !world->bvh_built) {
         if (src.fixed) return fail(RT_ERR_UNSUPPORTED, "the hierarchy of RT_FETCH_BVH is built and uploaded by the first rt_render_accumulate that asks for it");
         rtk::BvhHost &bvh = world->bvh_host;
-        rtk::build_bvh(world->h_rec32.data(), world->h_k.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
+        rtk::build_bvh(world->h_rec32.data(), world->h_km.data(), world->h_rad32.data(), world->h_rad32inv.data(), world->h_material.data(), world->n_spheres, bvh);
         // a previous attempt may have failed half way: start from nothing
-        for (void **buf : {&world->bvh_nodes, &world->bvh_spheres, &world->bvh_spheres_m, &world->bvh_lds_boxes, &world->bvh_lds_links})
+        for (void **buf : {&world->bvh_nodes, &world->bvh_spheres, &world->bvh_lds_boxes, &world->bvh_lds_links})
             if (*buf) { (void)hipFree(*buf); *buf = nullptr; }
         HIP_TRY(hipMalloc(&world->bvh_nodes, std::max<size_t>(64, bvh.nodes.size() * sizeof(rtk::BvhNode))));
         HIP_TRY(hipMalloc(&world->bvh_spheres, std::max<size_t>(64, bvh.spheres.size() * sizeof(rtk::BvhSphere))));
         if (!bvh.nodes.empty()) HIP_TRY(hipMemcpy(world->bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtk::BvhNode), hipMemcpyHostToDevice));
         if (!bvh.spheres.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres, bvh.spheres.data(), bvh.spheres.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
-        {
-            // the same leaf records with the mixed filter's -K' in place of K
-            std::vector<rtk::BvhSphere> lowered(bvh.spheres);
-            for (rtk::BvhSphere &sp : lowered) if (sp.index >= 0 && sp.index < world->n_spheres) sp.k = world->h_km[static_cast<size_t>(sp.index)];
-            HIP_TRY(hipMalloc(&world->bvh_spheres_m, std::max<size_t>(64, lowered.size() * sizeof(rtk::BvhSphere))));
-            if (!lowered.empty()) HIP_TRY(hipMemcpy(world->bvh_spheres_m, lowered.data(), lowered.size() * sizeof(rtk::BvhSphere), hipMemcpyHostToDevice));
-        }
         world->bvh_n_nodes = bvh.n_nodes;
         if (!bvh.lds_boxes.empty()) {
             HIP_TRY(hipMalloc(&world->bvh_lds_boxes, bvh.lds_boxes.size() * sizeof(rtk::BvhBoxLds)));
@@ -504,13 +492,11 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         for (int a = 0; a < 3; ++a) { p.bvh_origin[a] = bvh.origin[a]; p.bvh_step[a] = bvh.step[a]; }
         static_assert(sizeof(rtk::BvhSphere) == sizeof(p.bvh_big[0]), "big-sphere records are copied bytewise");
         std::memcpy(p.bvh_big, bvh.big, sizeof(rtk::BvhSphere) * static_cast<size_t>(bvh.n_big));
-        if (mixed) {
-            p.bvh_spheres = world->bvh_spheres_m;
-            for (int g = 0; g < bvh.n_big; ++g) p.bvh_big[g][3] = world->h_km[static_cast<size_t>(bvh.big[g].index)];
-        }
     }
-    p.sphere_rec = mixed ? world->rec32m : (f64 ? world->rec64 : (queue_mode ? world->rec32k : world->rec32));
-    p.filter_reach = world->filter_reach;
+    p.sphere_rec = queue_mode ? world->rec32m : (f64 ? world->rec64 : world->rec32);
+    // a world outside the range the filter's error bound needs: the throughput mode keeps every sphere of every ray
+    // (the mixed mode has handed such a world to the f64 kernel above)
+    p.filter_reach = world->filter_ok ? world->filter_reach : 3.402823466e+38f;
     p.sphere_center = f64 ? world->rec64 : world->rec32;
     p.sphere_radius = f64 ? world->rad64 : (precision == RT_PRECISION_F32 ? world->rad32inv : world->rad32);
     p.sphere_material = world->sphere_material;

@@ -60,6 +60,6 @@ struct BvhHost {
 };
 
 // centre_r2: n records {cx, cy, cz, r*r}; k, radius, inv_r, material: n values each
-void build_bvh(const float *centre_r2, const float *k, const float *radius, const float *inv_r, const int32_t *material, int32_t n, BvhHost &out);
+void build_bvh(const float *centre_r2, const float *k /* the filter constant of each sphere, -K' */, const float *radius, const float *inv_r, const int32_t *material, int32_t n, BvhHost &out);
 
 } // namespace rtk

@@ -12,32 +12,34 @@
 //   traced what.  Lanes idle only when the whole queue is empty.
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
-//   Mixed mode: f64 paths in the reference's operation order behind the throughput mode's f32 scan,
-//   used as a filter with an error margin that never drops a sphere the f64 test would hit (the
-//   bound is derived at the scan).  Lanes pool work as in throughput mode; every sample's colour is
+//   Mixed mode: f64 paths in the reference's operation order behind the f32 filter scan, whose
+//   error margin never drops a sphere the f64 test would hit (the bound is derived at the scan).  Lanes pool work as in throughput mode; every sample's colour is
 //   stored to its own slot and a second kernel adds the slots in sample order, so the image is the
 //   f64 literal mode's bit for bit.
-// Closest-hit scan (throughput mode)
-//   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1},
-//   K = |c|^2 - r^2, come through the scalar cache into SGPRs, the next group of four spheres
-//   being fetched while this one is tested.  Per sphere a lane spends 3 fused multiply-adds for
-//   h = d.c - d.o, 4 for a*c = a*K - 2a c.o + a|o|^2 and one for the discriminant h*h - a*c
-//   (main.odin:245-249 with the squares expanded and the per-ray and per-sphere parts
-//   hoisted), all as packed instructions on two spheres at once; a group of four spheres
-//   shares one compare.  Only when some lane's line meets a sphere of the group does the wave
-//   leave the straight-line code; such a lane queues (lane, sphere) in a per-wave queue in LDS, and
-//   the roots -- from the centre-to-line vector, whose rounding scales with the sphere and not with
-//   its distance -- and the range tests of main.odin:250-261 are evaluated later, 64 entries at a
+// Closest-hit scan (throughput and mixed mode)
+//   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, -K0,-K1},
+//   K = |c|^2 - r^2 lowered by an error margin, come through the scalar cache into SGPRs, the next group
+//   of four spheres being fetched while this one is tested.  The first stage is a conservative FILTER
+//   on the line of the ray, given by a unit direction e and the foot point f of the coordinate origin:
+//   r^2 - dist(c, line)^2 = (c.e)^2 - K + 2 c.f - |f|^2 (main.odin:245-249 divided by a, with the
+//   squares expanded and the per-ray and per-sphere parts hoisted).  Per sphere a lane spends 3 fused
+//   operations on h = c.e, one on h*h - K and 3 on adding 2 c.f, all as packed instructions on two
+//   spheres at once; a group of four spheres shares one compare with |f|^2.  The margins (derived at
+//   the scan) guarantee that no sphere with a non-negative exact discriminant is dropped, so the image
+//   is decided by the second stage alone.  Only when some lane's line meets a sphere of the group does
+//   the wave leave the straight-line code; such a lane queues (lane, sphere) in a per-wave queue in LDS,
+//   and the second stage -- throughput mode: the roots from the centre-to-line vector, whose rounding
+//   scales with the sphere and not with its distance; mixed mode: ray_sphere_intersection in f64 as
+//   written -- with the range tests of main.odin:250-261 is evaluated later, 64 entries at a
 //   time by whichever lanes are at hand, each result going to its owner through an LDS atomic
 //   minimum (the loop of main.odin:540-546 ends with the smallest accepted root, lowest index among
 //   equals, whatever the order of evaluation).  The literal modes park one sphere per lane instead
 //   and evaluate it when the lane needs the slot again, in sphere order with the shrinking t_max.
-//   The sphere a scattered segment starts on is tested before the scan with c = 0 (in f64 the
-//   reference sees |c| ~ 1e-15 there; in f32 the rounding of c would produce spurious
+//   Throughput mode: the sphere a scattered segment starts on is tested before the scan with c = 0 (in
+//   f64 the reference sees |c| ~ 1e-15 there; in f32 the rounding of c would produce spurious
 //   self-intersections).  BVH variants replace the list by a per-lane, stackless traversal of a
-//   bounding-volume hierarchy with the same per-sphere test; in the mixed mode the traversal runs in
-//   f32 on the rounded f64 ray with its box test widened by what that rounding can move, and a
-//   leaf's spheres go through the conservative filter and then the reference's f64 test.
+//   bounding-volume hierarchy with the same two stages per sphere; in the mixed mode the traversal runs
+//   in f32 on the rounded f64 ray with its box test widened by what that rounding can move.
 //   Literal modes: records {cx, cy, cz, r*r}, the reference's expressions as written.
 // Arithmetic
 //   Compiled with -ffp-contract=off: the only fused operations are the explicit fma calls -- those
@@ -606,27 +608,27 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             }
         };
         // the uncommon continuation for one sphere: some lane's line meets it
-        // mixed mode, per-ray values of the filter (set below): the origin's parameter on the filter's line, the lowered
+        // filter modes, per-ray values of the filter (set below): the origin's parameter on the filter's line, the lowered
         // threshold, and the bound below which the centre's parameter relative to the origin is certainly negative
         float s_o = 0.0f, thr_l = 0.0f, behind = 0.0f;
         skip_sphere = -1;
         auto park = [&](const auto h, const auto cc, const auto disc, const int i) {
             using T = decltype(disc);
-            // mixed mode: `disc` is the filter's value w, which carries the error margin (see below); a sphere is kept
+            // filter modes: `disc` is the filter's value w, which carries the error margin (see below); a sphere is kept
             // unless w is below the threshold, and a NaN keeps it
             bool meets;
-            if constexpr (MIXED) meets = !(disc < thr_l); else meets = (disc >= T(0));
+            if constexpr (FILTER) meets = !(disc < thr_l); else meets = (disc >= T(0));
             if (__builtin_amdgcn_ballot_w64(meets) != 0ull) {
                 // A line that meets the sphere only behind the origin (h <= 0) while the origin
                 // is outside it (cc >= 0) has both roots <= 0: never a hit, no need to park it.
                 // (the sphere the segment starts on was tested before the scan)
-                // Mixed mode: only when both signs are certain despite the f32 rounding -- the centre's parameter
+                // Filter modes: only when both signs are certain despite the f32 rounding -- the centre's parameter
                 // relative to the origin, hs, is below -behind, and hs^2 exceeds the lowered discriminant w - thr, which
                 // makes c = hs^2 - disc of main.odin:248 positive (per unit direction).
                 // (plain & and | on the lane predicates: each is a compare into a scalar mask and the combination scalar
                 // logic, where && and || would branch around the second compare)
                 bool ahead;
-                if constexpr (MIXED) {
+                if constexpr (FILTER) {
                     (void)cc;
                     const float hs = h - s_o, dl = disc - thr_l;
                     ahead = !((hs < -behind) & ((fma_rn(hs, hs, -dl) > 0.0f) | (i == skip_sphere)));
@@ -660,26 +662,23 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         // is tested.  One compare covers a group of four spheres: the largest of the four
         // discriminants (NaNs ignored) is negative in every lane for most groups.
         if constexpr (FILTER) {
-            // Throughput arithmetic.  The squares of main.odin:245-249 are expanded so that h and
-            // a*c are dot products of a per-sphere record {centre, K = |centre|^2 - r^2} with
-            // per-ray vectors:   h = d.centre - d.o      a*c = a*K - 2a centre.o + a|o|^2,
-            // each a chain of fused multiply-adds (the per-ray factors a*(-2o), a*|o|^2 and a are
-            // formed once per segment), and disc = fma(h, h, -(a*c)): 8 operations per sphere.
-            // Records are stored as PAIRS of spheres {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} and every
-            // operation is a packed one (v_pk_fma_f32) on two spheres at once: a plain VALU
-            // instruction with an SGPR source issues at half rate on gfx950, a packed one with an
-            // SGPR-pair source at full rate.  Pad records have K = FLT_MAX: a*c overflows and the
-            // discriminant is -inf.  `park` receives a*c where the literal modes pass c: only its
-            // sign is used there, and a > 0.
-            //
-            // Mixed mode: a filter on the f64 ray rounded to f32 that must never drop a sphere the f64 test of
-            // main.odin:245-261 would report as hit, in seven fused operations per sphere.  The ray becomes a unit
-            // direction e and the foot point f of the coordinate origin on its line (f.e = 0); then
+            // The closest-hit scan of the throughput and the mixed mode is a FILTER in seven fused f32 operations per
+            // sphere that must never drop a sphere whose exact discriminant (main.odin:249) is non-negative; what it
+            // keeps is decided by the second stage (throughput mode: the roots from the centre-to-line vector; mixed
+            // mode: ray_sphere_intersection as written, in f64), so the image does not depend on the filter's rounding.
+            // The ray (mixed mode: the f64 ray rounded to f32) becomes a unit direction e and the foot point f of the
+            // coordinate origin on its line (f.e = 0); then
             //     r^2 - dist(centre, line)^2 = (c.e)^2 - K + 2 c.f - |f|^2          (= disc / a of main.odin:249),
             //     h = c.e (3 operations),  w = fma(cz, 2fz, fma(cy, 2fy, fma(cx, 2fx, fma(h, h, -K)))) (4),
-            // and the sphere is kept unless w < |f|^2.  With u = 2^-24, S = |centre| + |o| + r and everything exact but
-            // the f32 roundings, w - |f|^2 differs from the f64 value by at most 43 u S^2: 18 from rounding d, o, centre
-            // and r to f32 and from the roundings of e and f (the line moves by at most 8 u S near a sphere it
+            // and the sphere is kept unless w < |f|^2.  Records are stored as PAIRS of spheres
+            // {cx0,cx1, cy0,cy1, cz0,cz1, -K0,-K1} and every operation is a packed one (v_pk_fma_f32) on two spheres
+            // at once: a plain VALU instruction with an SGPR source issues at half rate on gfx950, a packed one with
+            // an SGPR-pair source at full rate; -K is the addend of the square, the one place where an operation has
+            // both factors in vector registers and can take the record's pair as its third operand.  Pad records
+            // have -K = -FLT_MAX.
+            // Error bound: with u = 2^-24, S = |centre| + |o| + r and everything exact but the f32 roundings,
+            // w - |f|^2 differs from the exact value by at most 43 u S^2: 18 from rounding d, o, centre and r to f32
+            // and from the roundings of e and f (the line moves by at most 8 u S near a sphere it
             // meets), 10 because |e|^2 - 1 and f.e are not exactly zero (9 u and 13 u |o|), 10 from evaluating h and
             // w, 4 from |f|^2, 1 from the difference.  S^2 <= 3(|centre|^2 + r^2 + |o|^2), so lowering K and |f|^2 by
             // 2^-16 (|centre|^2 + r^2) and 2^-16 |o|^2 = 85 u S^2 in all covers it with 42 u S^2 to spare; the margin
@@ -689,11 +688,12 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             // certainly negative, and hs^2 > w - thr then means c = hs^2 - disc/a of main.odin:248 is positive (24 u S^2
             // for the error of hs^2): the line meets the sphere only behind an origin outside it.  The bound needs
             // every product to stay a normal f32 number: the world is checked for that on the host
-            // (2^-20 <= r, |centre| + r <= 2^20) and a ray outside 2^-40 <= |d|^2 <= 2^40, |o|^2 <= 2^40 (or not a number)
-            // keeps every sphere.  Division and square root are IEEE, so the CPU restatement forms the same values.
-            float d_o = 0.0f, o_o, fa;
+            // (2^-20 <= r, |centre| + r <= 2^20; the reach passed for any other world is FLT_MAX) and a ray outside
+            // 2^-40 <= |d|^2 <= 2^40, |o|^2 <= 2^40 (or not a number) keeps every sphere.  Division and square root are
+            // IEEE, so the CPU restatement forms the same values.
+            float o_o, fa;
             V3<float> fd, fo;
-            V3<float> fe = {0.0f, 0.0f, 0.0f}, f2 = {0.0f, 0.0f, 0.0f}; // mixed mode: unit direction, twice the foot point
+            V3<float> fe, f2; // unit direction, twice the foot point
             if constexpr (FMA) { fd = rd; fo = ro; fa = a; }
             else {
                 fd = {static_cast<float>(rd.x), static_cast<float>(rd.y), static_cast<float>(rd.z)};
@@ -701,15 +701,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 fa = dot(fd, fd);
             }
             o_o = dot(fo, fo);
-            // The sphere this segment starts on: its origin is the previous hit point, so c is zero
-            // up to the rounding of that point.  The reference's f64 arithmetic sees |c| ~ 1e-15
+            // Throughput mode, the sphere this segment starts on: its origin is the previous hit point, so c is
+            // zero up to the rounding of that point.  The reference's f64 arithmetic sees |c| ~ 1e-15
             // and its near root falls below t_min; in f32 the rounding of c is large enough to give
             // spurious hits just above t_min for short or grazing directions.  Take c = 0 for this
             // sphere: the roots of main.odin:249-258 become 0 and 2h/a, and only the second can be
             // a hit, for h > 0 (a segment through the inside).  It is tested first and left out
             // of the scan.
             if constexpr (FMA) {
-            d_o = dot(fd, fo);
             if (start_sphere >= 0) {
                 const float ocx = start_center.x - ro.x, ocy = start_center.y - ro.y, ocz = start_center.z - ro.z;
                 const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a; // (d.oc)/a as in `resolve`
@@ -717,9 +716,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 if (q > 0.0f && root >= t_min && root < closest) { closest = root; hit = start_sphere; }
             }
             }
-            float aox = 0.0f, aoy = 0.0f, aoz = 0.0f, aoo = 0.0f;
-            if constexpr (FMA) { aox = fa * (-2.0f * fo.x); aoy = fa * (-2.0f * fo.y); aoz = fa * (-2.0f * fo.z); aoo = fa * o_o; }
-            if constexpr (MIXED) {
+            {
                 const float nd = sqrt_rn(fa), inv_nd = 1.0f / nd;
                 fe = fd * inv_nd;
                 s_o = dot(fo, fe);
@@ -728,15 +725,16 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 f2 = {ft.x + ft.x, ft.y + ft.y, ft.z + ft.z};
                 reach_o = P.filter_reach + (abs_rn(fo.x) + abs_rn(fo.y) + abs_rn(fo.z));
                 behind = 1.9073486328125e-06f * reach_o; // 2^-19 = 32 u
-                // The sphere this segment starts on.  Its origin p = o' + t d' was a root of that sphere's equation,
-                // so c = |centre - p|^2 - r^2 (main.odin:248) is zero up to rounding: |c| <= 64 * 2^-53 (reach + |o'|)^2
+                // Mixed mode, the sphere this segment starts on.  Its origin p = o' + t d' was a root of that sphere's
+                // equation, so c = |centre - p|^2 - r^2 (main.odin:248) is zero up to rounding: |c| <= 64 * 2^-53 (reach + |o'|)^2
                 // (21 from the root and the hit point, 4 from evaluating c; o' the previous origin).  With the
                 // centre's parameter certainly below -behind/2 per unit direction, h of main.odin:247 is below
                 // -|d| behind/2, and the roots of main.odin:253-257 are <= 0 (c >= 0) or the far one is
                 // c/(h - sqrt(disc)) <= |c| / (2|h|) <= |c| / (|d| behind); below t_min the sphere cannot be hit and
                 // ray_sphere_intersection need not be evaluated for it.
-                skip_sphere = (start_sphere >= 0 && start_cc_bound < 9.0e-4f * (nd * behind)) ? start_sphere : -1;
-                const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f); // 2^-40, 2^40
+                if constexpr (MIXED) skip_sphere = (start_sphere >= 0 && start_cc_bound < 9.0e-4f * (nd * behind)) ? start_sphere : -1;
+                const bool in_range = (fa >= 9.094947017729282e-13f) && (fa <= 1.099511627776e12f) && (o_o <= 1.099511627776e12f) && // 2^-40, 2^40
+                                      (P.filter_reach <= 1048576.0f);
                 if (!in_range) {
                     // every sphere is a candidate of this ray: h = 0, w = -K', threshold the lowest number
                     fe = {0.0f, 0.0f, 0.0f}; f2 = {0.0f, 0.0f, 0.0f}; s_o = 0.0f;
@@ -760,16 +758,16 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 float closest_up = Lim<float>::max_v; // mixed mode: `closest` rounded up to f32, for the box tests
                 auto test_sphere = [&](const float cx, const float cy, const float cz, const float K, const float r2, const int index) {
                     ++bvh_tests;
+                    // stage 1: the list scan's conservative filter (the record holds -K' in place of K); a NaN keeps the sphere
+                    const float h = fma_rn(cz, fe.z, fma_rn(cy, fe.y, cx * fe.x));
+                    const float w = fma_rn(cz, f2.z, fma_rn(cy, f2.y, fma_rn(cx, f2.x, fma_rn(h, h, K))));
+                    if (w < thr_l) return;
+                    const float hs = h - s_o;
+                    if ((hs < -behind) && ((fma_rn(hs, hs, -(w - thr_l)) > 0.0f) || (index == skip_sphere))) return;
                     if constexpr (MIXED) {
-                        // the list scan's conservative filter (the record holds -K' in place of K), then
                         // ray_sphere_intersection as written (main.odin:245-261) in f64 and the caller's strict `<`
                         // (:542-545); equal roots go to the lower list index, which the list reaches first
                         (void)r2;
-                        const float h = fma_rn(cz, fe.z, fma_rn(cy, fe.y, cx * fe.x));
-                        const float w = fma_rn(cz, f2.z, fma_rn(cy, f2.y, fma_rn(cx, f2.x, fma_rn(h, h, K))));
-                        if (w < thr_l) return; // a NaN keeps the sphere
-                        const float hs = h - s_o;
-                        if ((hs < -behind) && ((fma_rn(hs, hs, -(w - thr_l)) > 0.0f) || (index == skip_sphere))) return;
 #ifdef RT_DIAG_COUNTERS
                         if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_parked; // one lane per execution by the wave (stats[7]; 5 and 6 hold the hierarchy's counts)
 #endif
@@ -788,11 +786,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                             closest_up = __double2float_ru(root);
                         }
                     } else {
-                    // stage 1: the list scan's filter
-                    const float h = fma_rn(cz, fd.z, fma_rn(cy, fd.y, fma_rn(cx, fd.x, -d_o)));
-                    const float m = fma_rn(K, fa, fma_rn(cz, aoz, fma_rn(cy, aoy, fma_rn(cx, aox, aoo))));
-                    const float disc = fma_rn(h, h, -m);
-                    if (!((disc >= 0.0f) && ((h > 0.0f) || (m < 0.0f)) && index != start_sphere)) return;
+                    if (index == start_sphere) return; // tested before the scan
                     // stage 2: the roots of `resolve`
                     const float ocx = cx - ro.x, ocy = cy - ro.y, ocz = cz - ro.z;
                     const float q = fma_rn(ocz, rd.z, fma_rn(ocy, rd.y, ocx * rd.x)) * inv_a;
@@ -839,7 +833,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 }
                 auto slack_of = [](const float a, const float b, const float c) { const float e = fma_rn(65535.0f, abs_rn(a), abs_rn(b)) + c; return (e < Lim<float>::max_v) ? e : 0.0f; };
                 float box_slack = 9.5367431640625e-07f * max_num(max_num(slack_of(ax, bx, ox_i), slack_of(ay, by, oy_i)), slack_of(az, bz, oz_i));
-                if constexpr (MIXED) { if (behind == Lim<float>::max_v) box_slack = Lim<float>::max_v; } // the ray is outside the filter's range
+                if (behind == Lim<float>::max_v) box_slack = Lim<float>::max_v; // the ray is outside the filter's range: every box
                 // does the segment [0, closest] meet the box {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16}?
                 // A NaN (0 * inf: an axis the ray does not move along) is ignored by min/max, which only widens the box.
                 auto meets_box = [&](const uint32_t w0, const uint32_t w1, const uint32_t w2) -> bool {
@@ -894,40 +888,27 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     }
                 }
             } else {
-            // per-ray factors, both halves alike: throughput mode d, -d.o, a(-2o), a|o|^2, a; mixed mode e and 2f
-            const F2 dx2 = MIXED ? F2{fe.x, fe.x} : F2{fd.x, fd.x}, dy2 = MIXED ? F2{fe.y, fe.y} : F2{fd.y, fd.y}, dz2 = MIXED ? F2{fe.z, fe.z} : F2{fd.z, fd.z};
-            const F2 ox2 = MIXED ? F2{f2.x, f2.x} : F2{aox, aox}, oy2 = MIXED ? F2{f2.y, f2.y} : F2{aoy, aoy}, oz2 = MIXED ? F2{f2.z, f2.z} : F2{aoz, aoz};
-            const F2 nd_o2 = {-d_o, -d_o}, oo2 = {aoo, aoo}, a2 = {fa, fa};
-            const float gate_at = MIXED ? thr_l : 0.0f;
+            // per-ray factors, both halves alike
+            const F2 ex2 = {fe.x, fe.x}, ey2 = {fe.y, fe.y}, ez2 = {fe.z, fe.z};
+            const F2 fx2 = {f2.x, f2.x}, fy2 = {f2.y, f2.y}, fz2 = {f2.z, f2.z};
             auto test_pairs = [&](const Pair &p, const Pair &q, const int i) {
-                F2 hp, hq, mp, mq, dp, dq;
-                if constexpr (MIXED) {
-                    // h = c.e, w = (h*h - K') + 2 c.f: seven packed operations per pair of spheres (p.k holds -K')
-                    hp = fma2(p.cz, dz2, fma2(p.cy, dy2, p.cx * dx2));
-                    hq = fma2(q.cz, dz2, fma2(q.cy, dy2, q.cx * dx2));
-                    dp = fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, fma2(hp, hp, p.k))));
-                    dq = fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, fma2(hq, hq, q.k))));
-                    mp = dp; mq = dq; // not used by `park` in this mode
-                } else {
-                    hp = fma2(p.cz, dz2, fma2(p.cy, dy2, fma2(p.cx, dx2, nd_o2)));
-                    hq = fma2(q.cz, dz2, fma2(q.cy, dy2, fma2(q.cx, dx2, nd_o2)));
-                    mp = fma2(p.k, a2, fma2(p.cz, oz2, fma2(p.cy, oy2, fma2(p.cx, ox2, oo2))));
-                    mq = fma2(q.k, a2, fma2(q.cz, oz2, fma2(q.cy, oy2, fma2(q.cx, ox2, oo2))));
-                    dp = fma2(hp, hp, -mp);
-                    dq = fma2(hq, hq, -mq);
-                }
+                // h = c.e, w = (h*h - K') + 2 c.f: seven packed operations per pair of spheres (p.k holds -K')
+                const F2 hp = fma2(p.cz, ez2, fma2(p.cy, ey2, p.cx * ex2));
+                const F2 hq = fma2(q.cz, ez2, fma2(q.cy, ey2, q.cx * ex2));
+                const F2 dp = fma2(p.cz, fz2, fma2(p.cy, fy2, fma2(p.cx, fx2, fma2(hp, hp, p.k))));
+                const F2 dq = fma2(q.cz, fz2, fma2(q.cy, fy2, fma2(q.cx, fx2, fma2(hq, hq, q.k))));
                 const float dmax = max_num(max_num(dp.x, dp.y), max_num(dq.x, dq.y));
 #ifdef RT_DIAG_NO_PARK
                 asm volatile("" :: "v"(dmax));
                 if (false) {
 #else
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= gate_at) != 0ull, 0)) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmax >= thr_l) != 0ull, 0)) {
 #endif
                     RT_DIAG_COUNT(diag_entries);
 #ifdef RT_DIAG_PHASES
                     ph_in = __builtin_amdgcn_s_memtime();
 #endif
-                    park(hp.x, mp.x, dp.x, i); park(hp.y, mp.y, dp.y, i + 1); park(hq.x, mq.x, dq.x, i + 2); park(hq.y, mq.y, dq.y, i + 3);
+                    park(hp.x, 0.0f, dp.x, i); park(hp.y, 0.0f, dp.y, i + 1); park(hq.x, 0.0f, dq.x, i + 2); park(hq.y, 0.0f, dq.y, i + 3);
 #ifdef RT_DIAG_PHASES
                     ph_slow += __builtin_amdgcn_s_memtime() - ph_in;
 #endif

@@ -4,7 +4,7 @@ Every f32 operation is a numpy float32 scalar operation (IEEE binary32, round to
 every fused multiply-add is evaluated exactly in rational arithmetic and rounded once, and the
 sample colours are summed as Q32.32 integers.  Written from the description of the arithmetic
 (the reference's expressions of ray-tracer/main.odin in f32, with the ray/sphere test in two
-stages, the start-sphere rule and reciprocal scaling), not from the C++ oracle, so that the
+stages -- a conservative filter, then the roots --, the start-sphere rule and reciprocal scaling), not from the C++ oracle, so that the
 oracle's f32 mode and the GPU kernel are pinned by something other than each other.
 Very slow (a rational fma per sphere test): a few thousand samples at most.
 """
@@ -138,23 +138,70 @@ def random_point_on_disk(g):  # main.odin:214-223
 
 
 # ---- the two-stage ray/sphere test
-def sphere_constant(c, r):
-    """K = |c|^2 - r^2 of the f32 centre and radius, formed in f64, rounded once"""
-    return F(float(c[0]) * float(c[0]) + float(c[1]) * float(c[1]) + float(c[2]) * float(c[2]) - float(r) * float(r))
+def filter_constant(c, r):
+    """-K' of the filter: K = |c|^2 - r^2 of the f32 centre and radius lowered by 2^-16 (|c|^2 + r^2), formed in f64;
+    K' is rounded down to f32, i.e. -K' up"""
+    c2 = float(c[0]) * float(c[0]) + float(c[1]) * float(c[1]) + float(c[2]) * float(c[2])
+    r2 = float(r) * float(r)
+    lowered = (c2 - r2) - (c2 + r2) * (1.0 / 65536.0)
+    kn = F(-lowered)
+    if float(kn) < -lowered:
+        kn = np.nextafter(kn, F(np.inf))
+    return F(kn)
+
+
+def filter_reach(spheres):
+    """max |c| + |r| over the f32 spheres, rounded up to f32; FLT_MAX when a sphere is outside the range the
+    filter's error bound needs (then every ray keeps every sphere)"""
+    reach, ok = 0.0, True
+    for c, r, _ in spheres:
+        far = math.sqrt(float(c[0]) * float(c[0]) + float(c[1]) * float(c[1]) + float(c[2]) * float(c[2])) + abs(float(r))
+        reach = max(reach, far)
+        if not (abs(float(r)) >= 1.0 / 1048576.0) or not (far <= 1048576.0):
+            ok = False
+    if not ok:
+        return F32_MAX
+    out = F(reach)
+    if float(out) < reach:
+        out = np.nextafter(out, F(np.inf))
+    return F(out)
 
 
 class Segment:
     """per-segment quantities of the test"""
 
-    def __init__(self, ro, rd):
+    def __init__(self, ro, rd, reach):
         self.o, self.d = ro, rd
-        self.d_o = dot(rd, ro)
         o_o = dot(ro, ro)
         self.a = dot(rd, rd)
-        self.ao = (self.a * (F(-2.0) * ro[0]), self.a * (F(-2.0) * ro[1]), self.a * (F(-2.0) * ro[2]))
-        self.aoo = self.a * o_o
         with np.errstate(divide="ignore"):
             self.inv_a = ONE / self.a
+        # stage 1, the conservative filter: unit direction e, foot point f of the coordinate origin on the line
+        nd = np.sqrt(self.a)
+        with np.errstate(divide="ignore"):
+            inv_nd = ONE / nd
+        self.e = (rd[0] * inv_nd, rd[1] * inv_nd, rd[2] * inv_nd)
+        self.s_o = dot(ro, self.e)
+        ft = (fma(-self.s_o, self.e[0], ro[0]), fma(-self.s_o, self.e[1], ro[1]), fma(-self.s_o, self.e[2], ro[2]))
+        self.thr = fma(F(-1.0 / 65536.0), o_o, dot(ft, ft))
+        self.f2 = (ft[0] + ft[0], ft[1] + ft[1], ft[2] + ft[2])
+        reach_o = reach + (abs(ro[0]) + abs(ro[1]) + abs(ro[2]))
+        self.behind = F(1.0 / 524288.0) * reach_o
+        self.in_range = bool(self.a >= F(2.0 ** -40) and self.a <= F(2.0 ** 40) and o_o <= F(2.0 ** 40) and reach <= F(1048576.0))
+
+    def keeps(self, c, kn):
+        """False only when the sphere's exact discriminant is certainly negative, or the line certainly meets the sphere
+        only behind an origin certainly outside it"""
+        if not self.in_range:
+            return True
+        h = fma(c[2], self.e[2], fma(c[1], self.e[1], c[0] * self.e[0]))
+        w = fma(c[2], self.f2[2], fma(c[1], self.f2[1], fma(c[0], self.f2[0], fma(h, h, kn))))
+        if w < self.thr:
+            return False
+        hs = h - self.s_o
+        if hs < -self.behind and fma(hs, hs, -(w - self.thr)) > ZERO:
+            return False
+        return True
 
     def q_of(self, c):
         oc = vsub(c, self.o)
@@ -169,14 +216,9 @@ class Segment:
             return root
         return t_max
 
-    def test(self, c, K, radius, t_max):
+    def test(self, c, kn, radius, t_max):
         d = self.d
-        h = fma(c[2], d[2], fma(c[1], d[1], fma(c[0], d[0], -self.d_o)))
-        m = fma(K, self.a, fma(c[2], self.ao[2], fma(c[1], self.ao[1], fma(c[0], self.ao[0], self.aoo))))
-        disc = fma(h, h, -m)
-        if not (disc >= ZERO):
-            return t_max
-        if not (h > ZERO or m < ZERO):
+        if not self.keeps(c, kn):
             return t_max
         oc, q = self.q_of(c)
         l = (fma(-q, d[0], oc[0]), fma(-q, d[1], oc[1]), fma(-q, d[2], oc[2]))
@@ -270,7 +312,8 @@ def render_region(width, height, region, cam, spheres, materials, seed):
     cam32 = {k: (v3(*v) if isinstance(v, tuple) else v) for k, v in cam.items()}
     dof_angle = F(cam["depth_of_field_angle"])
     sph = [(v3(*c), F(r), mi) for c, r, mi in spheres]
-    consts = [(sphere_constant(c, r), ONE / r) for c, r, _ in sph]
+    consts = [(filter_constant(c, r), ONE / r) for c, r, _ in sph]
+    reach = filter_reach(sph)
     mats = [(t, v3(*alb), F(p1)) for t, alb, p1 in materials]
     spp = cam["samples_per_pixel"]
     image, sums, segments = {}, {}, 0
@@ -295,7 +338,7 @@ def render_region(width, height, region, cam, spheres, materials, seed):
                     for bounce in range(cam["max_ray_bounces"] + 1):
                         segments += 1
                         closest, hit = F32_MAX, -1
-                        seg = Segment(ro, rd)
+                        seg = Segment(ro, rd, reach)
                         if start >= 0:
                             t = seg.from_surface(sph[start][0], closest)
                             if t < closest:
