@@ -961,18 +961,31 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 
         // ---------------- shading
         bool ended;
-        if (hit >= 0) {
-            const R4 sp = static_cast<const R4 *>(P.sphere_center)[hit];
+        const bool is_hit = hit >= 0;
+        R4 sp = {}, m = {};
+        int mtype = -1;
+        V3<Real> center = {Real(0), Real(0), Real(0)}, p = center, nrm = center;
+        bool front = false;
+        if (is_hit) {
+            sp = static_cast<const R4 *>(P.sphere_center)[hit];
             const Real radius = static_cast<const Real *>(P.sphere_radius)[hit];
             const int mi = P.sphere_material[hit];
-            const int mtype = P.material_type[mi];
-            const R4 m = static_cast<const R4 *>(P.material_rec)[mi];
+            mtype = P.material_type[mi];
+            m = static_cast<const R4 *>(P.material_rec)[mi];
             // hit record (main.odin:553-557)
-            const V3<Real> center = {sp.x, sp.y, sp.z};
-            const V3<Real> p = ro + closest * rd;
-            V3<Real> nrm = FMA ? (p - center) * radius : (p - center) / radius; // throughput mode: the array holds 1/r
-            const bool front = dot(rd, nrm) < Real(0);
+            center = {sp.x, sp.y, sp.z};
+            p = ro + closest * rd;
+            nrm = FMA ? (p - center) * radius : (p - center) / radius; // throughput mode: the array holds 1/r
+            front = dot(rd, nrm) < Real(0);
             nrm = front ? nrm : -nrm;
+        }
+        // One normalisation for the three places that normalise once per segment, each lane handing in the vector its
+        // own path normalises (so every lane computes exactly what it would compute in its own branch, in one pass
+        // of the wave through the square root and the divisions instead of three): the background's
+        // normalize(ray.direction) (main.odin:570), the dielectric's (:373) and the metals' normalize(reflect(...)) (:320).
+        V3<Real> unit = rd;
+        if (!is_hit || mtype != 0) unit = normalize<Real, FMA>((is_hit && mtype != 2) ? reflect(rd, nrm) : rd);
+        if (is_hit) {
             Draws g(ks, wp, static_cast<uint32_t>(bounce) + 1u);
             V3<Real> dir;
             V3<Real> atten = {m.x, m.y, m.z};
@@ -984,7 +997,6 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 Real dst = (ri >= Real(1)) ? ri : Real(1);
                 if (!front) { Real t = src; src = dst; dst = t; }
                 const Real rel = src / dst;
-                const V3<Real> unit = normalize<Real, FMA>(rd);
                 Real cos_theta = dot(-unit, nrm);
                 cos_theta = min_std(cos_theta, Real(1));
                 const Real sin2 = Real(1) - cos_theta * cos_theta;
@@ -1009,7 +1021,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     if (abs_rn(dir.x) <= EPS && abs_rn(dir.y) <= EPS && abs_rn(dir.z) <= EPS) dir = nrm;
                 } else {
                     // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
-                    dir = normalize<Real, FMA>(reflect(rd, nrm));
+                    dir = unit; // normalize(reflect(rd, nrm))
                     dir = dir + m.w * ruv;
                     if (mtype >= 4) {
                         // USE_METAL_FRESNEL with METAL_FRESNEL_KIND 0 (type 4: Schlick, main.odin:334-335, :111-122) or 1
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             RT_PHASE(ph_hit);
         } else {
             // background (main.odin:570-572, :412-418): lerp(a, b, t) = a*(1-t) + b*t
-            const V3<Real> d = normalize<Real, FMA>(rd);
+            const V3<Real> d = unit; // normalize(rd)
             const Real t = Real(0.5) * (d.y + Real(1));
             const V3<Real> wa = {Real(1), Real(1), Real(1)};
             const V3<Real> wb = {static_cast<Real>(0.5), static_cast<Real>(0.7), static_cast<Real>(1.0)};
