@@ -43,10 +43,11 @@ struct TileMap {
 
 struct RenderParams {
     // world, structure of arrays (device pointers)
-    const void *sphere_rec;     // scan records: float4 / double4 {cx, cy, cz, r*r}; throughput mode: per PAIR of spheres
-                                // {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1} with K = |c|^2 - r*r; mixed mode: the same
-                                // pairs with K lowered by the filter's margin 2^-17 (|c|^2 + r*r)
-    float filter_reach;         // mixed mode: max over spheres of |c| + |r|, rounded up
+    const void *sphere_rec;     // scan records: float4 / double4 {cx, cy, cz, r*r}; throughput and mixed mode: per PAIR
+                                // of spheres {cx0,cx1, cy0,cy1, cz0,cz1, -K'0,-K'1}, K' = |c|^2 - r*r lowered by the
+                                // filter's margin 2^-16 (|c|^2 + r*r)
+    float filter_reach;         // filter modes: max over spheres of |c| + |r|, rounded up; FLT_MAX for a world outside the
+                                // range of the filter's error bound (every ray then keeps every sphere)
     const void *sphere_center;  // float4 / double4 {cx, cy, cz, r*r}: the centre is read from here on a hit
     const void *sphere_radius;  // per sphere radius, float / double (throughput mode: 1/radius)
     const int32_t *sphere_material;

@@ -983,8 +983,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         // own path normalises (so every lane computes exactly what it would compute in its own branch, in one pass
         // of the wave through the square root and the divisions instead of three): the background's
         // normalize(ray.direction) (main.odin:570), the dielectric's (:373) and the metals' normalize(reflect(...)) (:320).
+        // (list scan only: through the hierarchy, where the kernels are built for more waves per SIMD, the longer live
+        // ranges cost more in spilled registers than the shared pass saves; each branch normalises for itself there)
+        constexpr bool SHARED_NORMALIZE = BVH == 0;
         V3<Real> unit = rd;
-        if (!is_hit || mtype != 0) unit = normalize<Real, FMA>((is_hit && mtype != 2) ? reflect(rd, nrm) : rd);
+        if constexpr (SHARED_NORMALIZE) {
+            if (!is_hit || mtype != 0) unit = normalize<Real, FMA>((is_hit && mtype != 2) ? reflect(rd, nrm) : rd);
+        }
+        auto normalized = [&](const V3<Real> x) -> V3<Real> { if constexpr (SHARED_NORMALIZE) { (void)x; return unit; } else return normalize<Real, FMA>(x); };
         if (is_hit) {
             Draws g(ks, wp, static_cast<uint32_t>(bounce) + 1u);
             V3<Real> dir;
@@ -997,7 +1003,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 Real dst = (ri >= Real(1)) ? ri : Real(1);
                 if (!front) { Real t = src; src = dst; dst = t; }
                 const Real rel = src / dst;
-                Real cos_theta = dot(-unit, nrm);
+                const V3<Real> unit_d = normalized(rd);
+                Real cos_theta = dot(-unit_d, nrm);
                 cos_theta = min_std(cos_theta, Real(1));
                 const Real sin2 = Real(1) - cos_theta * cos_theta;
                 const bool must_reflect = (rel * rel * sin2) > Real(1);
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     const Real refl = r0 + (Real(1) - r0) * qq * qq * qq * qq * qq;
                     do_reflect = refl > g.next<Real>();
                 }
-                dir = do_reflect ? reflect(unit, nrm) : refract(unit, nrm, rel);
+                dir = do_reflect ? reflect(unit_d, nrm) : refract(unit_d, nrm, rel);
                 atten = {Real(1), Real(1), Real(1)};
             } else {
                 const V3<Real> ruv = random_unit_vector<Real, FMA>(g);
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     if (abs_rn(dir.x) <= EPS && abs_rn(dir.y) <= EPS && abs_rn(dir.z) <= EPS) dir = nrm;
                 } else {
                     // metallic_proc without the Fresnel block (main.odin:315-323, :348-353)
-                    dir = unit; // normalize(reflect(rd, nrm))
+                    dir = normalized(reflect(rd, nrm));
                     dir = dir + m.w * ruv;
                     if (mtype >= 4) {
                         // USE_METAL_FRESNEL with METAL_FRESNEL_KIND 0 (type 4: Schlick, main.odin:334-335, :111-122) or 1
@@ -1080,7 +1087,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             RT_PHASE(ph_hit);
         } else {
             // background (main.odin:570-572, :412-418): lerp(a, b, t) = a*(1-t) + b*t
-            const V3<Real> d = unit; // normalize(rd)
+            const V3<Real> d = normalized(rd);
             const Real t = Real(0.5) * (d.y + Real(1));
             const V3<Real> wa = {Real(1), Real(1), Real(1)};
             const V3<Real> wb = {static_cast<Real>(0.5), static_cast<Real>(0.7), static_cast<Real>(1.0)};
