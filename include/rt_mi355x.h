@@ -94,16 +94,17 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 /* ---- options ------------------------------------------------------------ */
 
 /* arithmetic the kernel computes in */
-#define RT_PRECISION_F32 0         /* f32 paths, fused multiply-adds in the ray/sphere test, exact Q32.32 sample
-                                      sums, f64 mean and square root (throughput path).  The sphere a scattered
+#define RT_PRECISION_F32 0         /* f32 paths, fused multiply-adds in the ray/sphere test (a conservative filter in
+                                      seven operations per sphere, then the roots of the spheres it keeps), exact Q32.32
+                                      sample sums, f64 mean and square root (throughput path).  The sphere a scattered
                                       segment starts on is tested with c = 0 (main.odin:247 evaluates to ~1e-15
                                       there in f64; its f32 rounding would give spurious self-intersections)   */
 #define RT_PRECISION_F64 1         /* f64, the reference's literal operation order (main.odin:19 is f64)      */
 #define RT_PRECISION_F32_LITERAL 2 /* f32, the reference's literal operation order, no fused multiply-adds    */
 #define RT_PRECISION_MIXED 3       /* the image of RT_PRECISION_F64 (with one sample chunk: f64, literal order,
                                       colours summed in sample order, main.odin:575) bit for bit, traced faster:
-                                      the f32 scan of RT_PRECISION_F32 runs on the f64 ray rounded to f32 as a
-                                      conservative filter -- a sphere is skipped only when its discriminant
+                                      the f32 filter scan of RT_PRECISION_F32 runs on the f64 ray rounded to f32
+                                      -- a sphere is skipped only when its discriminant
                                       (main.odin:249) is negative by more than the f32 rounding can explain --
                                       and every sphere it keeps goes through ray_sphere_intersection as written
                                       (main.odin:245-261) in f64; hit record, scattering and colour are f64.

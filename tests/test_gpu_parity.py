@@ -706,7 +706,7 @@ def test_mixed_headline_frame_against_f64_kernel_and_f32_floor(rt, oracle):
     frac_8bit = float(np.mean(np.all(rt.quantize_rgb8(img) == rt.quantize_rgb8(ref_img), axis=2)))
     print(f"final 1200x675x500: f32 vs f64 arithmetic: {frac_1e4:.4f} within 1e-4, {frac_8bit:.4f} identical at 8 bit; "
           f"segments f32/f64 {int(st[0]) / int(st_ref[0]):.6f}; mixed kernel {int(st_ref[2]) / 1e6:.1f} ms, f32 {int(st[2]) / 1e6:.1f} ms")
-    assert frac_1e4 >= 0.78 and frac_8bit >= 0.965
+    assert frac_1e4 >= 0.80 and frac_8bit >= 0.975      # measured 0.8142 and 0.9814
     assert abs(int(st[0]) / int(st_ref[0]) - 1.0) < 1e-4
     assert abs(float(lin.mean() / ref_lin.mean()) - 1.0) < 2e-4
 
