@@ -646,6 +646,11 @@ def test_mixed_outside_the_filter_range_and_far_camera(rt, oracle):
         assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0]), scale
         image, _, stats = gpu_render(rt, c2, cam, s2, mat, seed=9, precision=rt.PRECISION_MIXED, sphere_fetch=rt.FETCH_BVH)
         assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0]), scale
+        # the throughput mode shares the filter: outside its range every ray keeps every sphere and the roots decide
+        ref32 = oracle.render_region(w, h, (0, 0, w, h), cam, s2, mat, precision=rt.PRECISION_F32, seed=9, threads=4)
+        for fetch in (rt.FETCH_AUTO, rt.FETCH_BVH, rt.FETCH_LDS):
+            image, _, stats = gpu_render(rt, c2, cam, s2, mat, seed=9, precision=rt.PRECISION_F32, sphere_fetch=fetch)
+            assert np.array_equal(image, ref32["image"]) and int(stats[0]) == int(ref32["stats"][0]), (scale, fetch)
     far = rt.CameraSettings.from_buffer_copy(cs)
     eye = np.array([-2000.0, 2000.0, 1000.0]) * 1.7
     far.position = rt.V3(*eye)

@@ -270,6 +270,31 @@ def test_f32_throughput_arithmetic_against_python_statement(rt, oracle):
     assert int(r["stats"][0]) == seg
 
 
+def test_throughput_mode_outside_the_filter_range_against_python_statement(rt, oracle):
+    """a world scaled beyond the range the filter's error bound needs: every ray keeps every sphere, the roots of
+    stage 2 decide; oracle against tests/pyref32.py"""
+    cs, sph, mat = rt.build_dev_scene(16)
+    cs.samples_per_pixel = 2
+    for scale in (1e-7, 1e7):
+        s2 = sph.copy()
+        s2["center"] *= scale
+        s2["radius"] *= scale
+        c2 = rt.CameraSettings.from_buffer_copy(cs)
+        c2.position = rt.V3(*(np.array(cs.position.tuple()) * scale))
+        c2.focus_distance = cs.focus_distance * scale
+        cam = rt.calculate_camera_render_data(c2)
+        w, h = c2.image_width, c2.image_height
+        region = (3, 2, 11, 7)
+        a = oracle.render_region(w, h, region, cam, s2, mat, precision=rt.PRECISION_F32, seed=23)
+        spl = [(tuple(x["center"]), float(x["radius"]), int(x["material_index"])) for x in s2]
+        ml = [(int(m["type"]), tuple(m["albedo"]), float(m["param1"])) for m in mat]
+        assert pyref32.filter_reach([(pyref32.v3(*c), pyref32.F(r), mi) for c, r, mi in spl]) == pyref32.F32_MAX
+        img, sums, seg = pyref32.render_region(w, h, region, cam_dict(cam), spl, ml, 23)
+        for (u, v), rgb in img.items():
+            assert tuple(a["image"][v, u]) == rgb, (scale, u, v)
+        assert seg == int(a["stats"][0])
+
+
 def test_exact_fma_of_the_python_statement():
     """pyref32.fma rounds once: cases where rounding the f64 result of a*b+c to f32 would round twice"""
     F = np.float32
