@@ -170,11 +170,8 @@ template <typename Real> __device__ __forceinline__ V3<Real> refract(V3<Real> v,
 }
 
 // ----------------------------------------------------------------------------- the kernel
-template <typename Real> __device__ __forceinline__ const Real *camera_of(const RenderParams &p);
-template <> __device__ __forceinline__ const float *camera_of<float>(const RenderParams &p) { return p.cam32.v; }
-template <> __device__ __forceinline__ const double *camera_of<double>(const RenderParams &p) { return p.cam64.v; }
-
-template <typename Real> __device__ __forceinline__ V3<Real> cam3(const Real *c, int i) { return {c[3 * i], c[3 * i + 1], c[3 * i + 2]}; }
+template <typename Real, typename Ptr> __device__ __forceinline__ V3<Real> cam3(Ptr c, int i) { return {c[3 * i], c[3 * i + 1], c[3 * i + 2]}; }
+template <typename Real> constexpr size_t camera_offset() { return std::is_same<Real, double>::value ? offsetof(RenderParams, cam64) : offsetof(RenderParams, cam32); }
 
 __device__ __forceinline__ int tile_row_of(const TileMap &m, int k) {
     return ((k / m.rows_per_strip) * m.strip_count + m.strip_index) * m.rows_per_strip + (k % m.rows_per_strip);
@@ -289,7 +286,6 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     };
 
     const int lane = threadIdx.x & 63;
-    const Real *C = camera_of<Real>(P);
 
     // ---- the work a lane is on: pixel (u, v), sample s (index within the call)
     int u = 0, v = 0;
@@ -414,8 +410,16 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             Draws g(ks, wp, 0u);
             Real jx = g.range_pm_half<Real>();
             Real jy = g.range_pm_half<Real>();
-            V3<Real> psp = cam3(C, 3) + (static_cast<Real>(u) + jx) * cam3(C, 1) + (static_cast<Real>(v) + jy) * cam3(C, 2);
-            ro = cam3(C, 0);
+            // The 19 camera constants are read here, through the scalar cache from the kernel's argument segment, every
+            // time a wave starts camera rays: kept in scalar registers across the scan they are spilled to vector
+            // lanes and read back one by one (mixed mode: 1 % of the frame).  The opaque zero keeps the loads in the loop
+            // (list scan; through the hierarchy, with fewer scalar registers in use, the compiler's placement is as good).
+            typedef const Real __attribute__((address_space(4))) *ConstCam;
+            int opaque_zero = 0;
+            if constexpr (BVH == 0) asm volatile("" : "+s"(opaque_zero));
+            ConstCam C = (ConstCam)((const char __attribute__((address_space(4))) *)(__builtin_amdgcn_kernarg_segment_ptr()) + camera_offset<Real>()) + opaque_zero;
+            V3<Real> psp = cam3<Real>(C, 3) + (static_cast<Real>(u) + jx) * cam3<Real>(C, 1) + (static_cast<Real>(v) + jy) * cam3<Real>(C, 2);
+            ro = cam3<Real>(C, 0);
             if (C[18] > Real(0)) {
                 // random_point_on_disk (main.odin:214-223)
                 Real px = Real(0), py = Real(0);
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     py = g.range_pm1<Real>();
                     if (px * px + py * py <= Real(1)) break;
                 }
-                ro = ro + ((px * cam3(C, 4)) + (py * cam3(C, 5)));
+                ro = ro + ((px * cam3<Real>(C, 4)) + (py * cam3<Real>(C, 5)));
             }
             rd = psp - ro;
             color = {Real(1), Real(1), Real(1)};
