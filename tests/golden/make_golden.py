@@ -9,6 +9,11 @@ render_<scene>_f32.npz  the same renders in the two f32 arithmetics: the through
                         fused multiply-adds, independent of the C++ oracle and of the GPU; the literal f32 mode
                         ("literal") computed by the C++ oracle (a regression pin)
 intersection_kat.json   ray_sphere_intersection cases with closed-form answers
+scatter_kat.json        material_scatter (main.odin:292-410) known answers per material -- lambertian, metal (absorbing and not, the
+                        Fresnel kinds), glass front / back face / total internal reflection, air bubble -- with the draws of fixed
+                        streams, computed by tests/pyref.py in IEEE f64 (numbers as C99 hex floats)
+filter_kat.json         the candidate filter of the throughput and mixed modes for single rays and spheres (grazing, through, behind,
+                        far cameras, out-of-range rays): kept / dropped and its two f32 values, computed by tests/pyref32.py
 No reference source or reference output is involved: the reference ships no vectors for this path.
 """
 import importlib
@@ -97,6 +102,68 @@ def main():
         dict(o=[0, 0, 0], d=[0, 0, -1], c=[0, 0, -5], r=-1, t_min=0.001, t_max=1e30, t=4.0, note="r*r"),
     ]
     json.dump(cases, open(os.path.join(HERE, "intersection_kat.json"), "w"), indent=1)
+
+    # material_scatter known answers (tests/pyref.py, f64)
+    materials = [
+        ("lambertian", (0, (0.8, 0.6, 0.2), 0.0), (0.3, -1.0, 0.2), True),
+        ("metal fuzz 0", (1, (0.7, 0.6, 0.5), 0.0), (0.3, -1.0, 0.2), True),
+        ("metal fuzz 1 grazing (may absorb)", (1, (0.8, 0.6, 0.2), 1.0), (1.0, -0.05, 0.0), True),
+        ("metal, Fresnel kind 2", (3, (0.7, 0.6, 0.5), 0.1), (0.3, -1.0, 0.2), True),
+        ("metal, Schlick kind 0", (4, (0.7, 0.6, 0.5), 0.1), (0.3, -1.0, 0.2), True),
+        ("metal, Hoffman kind 1", (5, (0.7, 0.6, 0.5), 0.1), (1.0, -0.02, 0.3), True),
+        ("glass front face", (2, (0.0, 0.0, 0.0), 1.5), (0.3, -1.0, 0.2), True),
+        ("glass back face, steep: total internal reflection", (2, (0.0, 0.0, 0.0), 1.5), (1.0, -0.2, 0.0), False),
+        ("glass back face, shallow", (2, (0.0, 0.0, 0.0), 1.5), (0.1, -1.0, 0.0), False),
+        ("air bubble ri < 1", (2, (0.0, 0.0, 0.0), 1.0 / 1.5), (0.2, -1.0, 0.1), True),
+        ("air bubble back face", (2, (0.0, 0.0, 0.0), 1.0 / 1.5), (0.9, -0.3, 0.1), False),
+    ]
+    hx = lambda v: [float(x).hex() for x in v]
+    kat = []
+    hit_p, ray_o, normal = (0.5, 0.25, -1.0), (0.0, 2.0, 0.0), (0.0, 1.0, 0.0)
+    for name, material, ray_d, front in materials:
+        for sample in range(6):
+            keys = (99, 1234, sample, 3)
+            (po, pd), att, ok = pyref.material_scatter(material, ray_o, ray_d, hit_p, normal, front, pyref.Gen(*keys))
+            kat.append(dict(note=name, type=material[0], albedo=hx(material[1]), param1=float(material[2]).hex(), ray_o=hx(ray_o), ray_d=hx(ray_d), hit_p=hx(hit_p),
+                            normal=hx(normal), front=front, seed=keys[0], pixel=keys[1], sample=keys[2], bounce=keys[3],
+                            out_origin=hx(po), out_direction=hx(pd), attenuation=hx(att), ok=bool(ok)))
+    json.dump(kat, open(os.path.join(HERE, "scatter_kat.json"), "w"), indent=1)
+
+    # the candidate filter (tests/pyref32.py): ray (f64, rounded to f32 by the filter), sphere, reach -> kept, values
+    rng = np.random.default_rng(4711)
+    F = pyref32.F
+    fk = []
+    def add(note, o, d, c, r):
+        cf = (F(c[0]), F(c[1]), F(c[2]))
+        sph = [(cf, F(r), 0)]
+        reach = pyref32.filter_reach(sph)
+        seg = pyref32.Segment((F(o[0]), F(o[1]), F(o[2])), (F(d[0]), F(d[1]), F(d[2])), reach)
+        kn = pyref32.filter_constant(cf, F(r))
+        with np.errstate(all="ignore"):
+            hs, dl, _ = seg.filter_values(cf, kn)
+        fk.append(dict(note=note, o=hx(o), d=hx(d), c=hx(c), r=float(r).hex(), reach=float(reach).hex(), in_range=bool(seg.in_range),
+                       kept=bool(seg.keeps(cf, kn)), hs=float(hs).hex() if seg.in_range else None, disc=float(dl).hex() if seg.in_range else None,
+                       behind=float(seg.behind).hex()))
+    add("head-on", (0, 0, 0), (0, 0, -1), (0, 0, -5), 1.0)
+    add("behind the origin", (0, 0, 0), (0, 0, 1), (0, 0, -5), 1.0)
+    add("origin inside, centre behind", (0, 0, 0.5), (0, 0, 1), (0, 0, 0), 1.0)
+    add("clear miss", (0, 3, 0), (0, 0, -1), (0, 0, -5), 1.0)
+    add("direction out of range (tiny)", (0, 0, 0), (0, 0, -1e-25), (0, 0, -5), 1.0)
+    add("origin out of range", (2e7, 0, 0), (0, 1, 0), (0, 0, -5), 1.0)
+    add("radius out of range", (0, 0, 0), (0, 0, -1), (0, 0, -5), 1e-8)
+    for k in range(40):
+        scale = 10.0 ** rng.uniform(-2, 3)
+        c = rng.normal(size=3) * scale
+        r = scale * 10.0 ** rng.uniform(-2, 0.3)
+        o = c + rng.normal(size=3) * r * 10.0 ** rng.uniform(0, 3)
+        t = rng.normal(size=3)
+        oc = c - o
+        t -= oc * (t @ oc) / (oc @ oc)
+        t /= np.linalg.norm(t)
+        target = c + t * r * (1.0 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-7, -1))   # grazing, either side
+        d = (target - o) * rng.choice([1.0, -1.0]) * 10.0 ** rng.uniform(-3, 3)
+        add("grazing %d" % k, tuple(o), tuple(d), tuple(c), float(r))
+    json.dump(fk, open(os.path.join(HERE, "filter_kat.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

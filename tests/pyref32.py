@@ -189,17 +189,21 @@ class Segment:
         self.behind = F(1.0 / 524288.0) * reach_o
         self.in_range = bool(self.a >= F(2.0 ** -40) and self.a <= F(2.0 ** 40) and o_o <= F(2.0 ** 40) and reach <= F(1048576.0))
 
+    def filter_values(self, c, kn):
+        """(hs, w - thr): the centre's parameter relative to the origin and the lowered discriminant, per unit direction"""
+        h = fma(c[2], self.e[2], fma(c[1], self.e[1], c[0] * self.e[0]))
+        w = fma(c[2], self.f2[2], fma(c[1], self.f2[1], fma(c[0], self.f2[0], fma(h, h, kn))))
+        return h - self.s_o, w - self.thr, w
+
     def keeps(self, c, kn):
         """False only when the sphere's exact discriminant is certainly negative, or the line certainly meets the sphere
         only behind an origin certainly outside it"""
         if not self.in_range:
             return True
-        h = fma(c[2], self.e[2], fma(c[1], self.e[1], c[0] * self.e[0]))
-        w = fma(c[2], self.f2[2], fma(c[1], self.f2[1], fma(c[0], self.f2[0], fma(h, h, kn))))
+        hs, dl, w = self.filter_values(c, kn)
         if w < self.thr:
             return False
-        hs = h - self.s_o
-        if hs < -self.behind and fma(hs, hs, -(w - self.thr)) > ZERO:
+        if hs < -self.behind and fma(hs, hs, -dl) > ZERO:
             return False
         return True
 

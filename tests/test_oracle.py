@@ -182,6 +182,31 @@ def test_metal_fresnel_render_against_pyref(rt, oracle, mtype):
     assert int(plain["stats"][0]) == seg and not np.array_equal(plain["image"], r["image"])  # same paths, brighter gold
 
 
+def test_scatter_known_answers(oracle):
+    """tests/golden/scatter_kat.json (computed by tests/pyref.py): the oracle's f64 material_scatter, bit for bit"""
+    kat = json.load(open(os.path.join(GOLDEN, "scatter_kat.json")))
+    fx = lambda v: tuple(float.fromhex(x) for x in v)
+    assert len(kat) >= 60 and {k["type"] for k in kat} == {0, 1, 2, 3, 4, 5} and any(not k["ok"] for k in kat)
+    for k in kat:
+        material = (k["type"], fx(k["albedo"]), float.fromhex(k["param1"]))
+        o_, d_, att, ok = oracle.material_scatter(1, material, fx(k["ray_o"]), fx(k["ray_d"]), fx(k["hit_p"]), fx(k["normal"]), k["front"],
+                                                 k["seed"], k["pixel"], k["sample"], k["bounce"])
+        assert ok == k["ok"] and tuple(o_) == fx(k["out_origin"]) and tuple(d_) == fx(k["out_direction"]) and tuple(att) == fx(k["attenuation"]), k["note"]
+
+
+def test_filter_known_answers(oracle):
+    """tests/golden/filter_kat.json (computed by tests/pyref32.py): the oracle's restatement of the candidate filter
+    gives the same decision and the same two f32 values"""
+    kat = json.load(open(os.path.join(GOLDEN, "filter_kat.json")))
+    fx = lambda v: tuple(float.fromhex(x) for x in v)
+    assert sum(k["kept"] for k in kat) >= 10 and sum(not k["kept"] for k in kat) >= 10 and sum(not k["in_range"] for k in kat) >= 3
+    for k in kat:
+        f = oracle.mixed_filter(fx(k["o"]), fx(k["d"]), fx(k["c"]), float.fromhex(k["r"]), float.fromhex(k["reach"]))
+        assert f["in_range"] == k["in_range"] and f["kept"] == k["kept"], k["note"]
+        if k["in_range"]:
+            assert f["h"] == float.fromhex(k["hs"]) and f["disc"] == float.fromhex(k["disc"]) and f["behind"] == float.fromhex(k["behind"]), k["note"]
+
+
 def test_total_internal_reflection_draws_nothing(oracle):
     # steep back-face hit in glass: must_reflect short-circuits the uniform draw (main.odin:390), so the
     # outcome cannot depend on the stream
