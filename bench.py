@@ -273,6 +273,7 @@ def main():
         if world_size > 1:
             partition = (f"8-row strips dealt over the ranks, gather of each rank's rows to rank 0 ({backend})" if args.partition == "rows"
                          else f"sample split, all-reduce of the Q32.32 accumulators ({backend})")
+        traffic = measured_traffic(args) if not args.fetch.startswith("bvh") else None
         out = {
             "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak" if (args.scene, w, total_spp) == ("final", 1200, 500)
                       else f"Msamples/sec (whole node), {args.scene} scene {w}x{h} {total_spp}spp; % FP32 VALU peak",
@@ -286,8 +287,9 @@ def main():
             "segments_per_sample": m["segments"] / max(1, m["samples_rank"]),
             "lane_utilization": m["segments"] / max(1, 64 * m["wave_iters"]),
             "roofline": {"bound": "valu_fp32", "achieved": m["achieved"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": m["achieved"] / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic(args) if not args.fetch.startswith("bvh") else None,
-                         "traffic_source": f"{PMC_SUMMARY} (rocprofv3 --pmc passes over this command; not measured in this run)",
+                         "traffic": traffic,
+                         "traffic_source": f"{PMC_SUMMARY} (rocprofv3 --pmc passes over this command; not measured in this run)" if traffic is not None
+                                           else "none: the committed rocprofv3 passes cover the default single-GPU workload only",
                          "algorithmic_bytes": w * h * 24 + len(sph) * 16,
                          "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator/staging stores and atomics are a few % of HBM bandwidth",
                          "kernel": tag, "kernel_ms": m["kernel_s"] * 1e3, "flop_per_test": F_TEST, "sphere_tests_per_launch": m["tests_rank"]},
