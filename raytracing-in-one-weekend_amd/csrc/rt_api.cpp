@@ -246,7 +246,7 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
     const size_t ns_alloc = ns_pad + rtk::GROUP;
     std::vector<float> rec32(4 * ns_alloc, 0.0f), rec32m(4 * ns_alloc, 0.0f), rad32(ns), rad32inv(ns), mat32(4 * nm);
     std::vector<double> rec64(4 * ns_alloc, 0.0), rad64(ns), mat64(4 * nm);
-    // throughput records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
+    // the filter's records are stored per pair of spheres: {cx0,cx1, cy0,cy1, cz0,cz1, -K'0,-K'1}
     auto pair_slot = [](size_t i, int component) { return 8 * (i / 2) + 2 * component + (i % 2); };
     for (size_t i = ns; i < ns_alloc; ++i) { rec32[4 * i + 3] = -INFINITY; rec64[4 * i + 3] = -INFINITY; rec32m[pair_slot(i, 3)] = -3.402823466e+38f; }
     double reach = 0.0;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         for (int i = threadIdx.x; i < 8 * P.bvh_n_nodes; i += BVH_LDS_BLOCK_THREADS) l_links[i] = gl[i];
         __syncthreads();
     }
-    // throughput mode: pair j = spheres 2j and 2j+1 as {cx0,cx1, cy0,cy1, cz0,cz1, K0,K1}
+    // filter modes: pair j = spheres 2j and 2j+1 as {cx0,cx1, cy0,cy1, cz0,cz1, -K'0,-K'1}
     auto pair = [&](int j) -> Pair {
         Pair p;
         if constexpr (FETCH == FETCH_LDS) {
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) ++diag_resolves; // one lane per execution by the wave
 #endif
             if constexpr (FMA) {
-                // Throughput arithmetic: the scan's discriminant h^2 - a*c is the difference of two
-                // numbers of size a*|centre - o|^2 and only selects candidates.  A candidate's roots
+                // Throughput arithmetic: the scan's filter value is a difference of numbers of the size of
+                // |centre|^2 and only selects candidates.  A candidate's roots
                 // come from the vector l from the centre to the line's closest point, whose length
                 // is at most of the size of the radius:
                 //     oc = centre - o,  q = (d.oc)/a,  l = oc - q*d,  D = r^2 - |l|^2,
