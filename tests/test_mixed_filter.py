@@ -55,7 +55,7 @@ def cases(rng, n):
 
 def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
     rng = np.random.default_rng(2024)
-    worst_low, worst_high, worst_h, kept, total = None, None, 0.0, 0, 0
+    worst_low, worst_high, worst_h, worst_rounding, kept, total = None, None, 0.0, Fraction(0), 0, 0
     for o, d, c, r in cases(rng, 6000):
         cf = np.float32(c).astype(np.float64)
         reach = float(np.linalg.norm(cf) + abs(np.float32(r))) * 1.000001
@@ -74,6 +74,12 @@ def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
         # the margin (>= 85 u S^2) exceeds the rounding (<= 43 u S^2) by more than that
         assert lowered >= exact + 24 * unit, (o, d, c, r)
         gap = (lowered - exact) / unit
+        # the rounding itself (what is left after taking the margin 2^-16 (|c|^2 + r^2 + |o|^2) of the f32 inputs off): within the derived 43 u S^2
+        c32, o32, r32 = (Fraction(float(np.float32(x))) for x in c), (Fraction(float(np.float32(x))) for x in o), Fraction(float(np.float32(r)))
+        margin = (sum(x * x for x in c32) + r32 * r32 + sum(x * x for x in o32)) / 65536
+        rounding = (lowered - exact - margin) / unit
+        assert abs(rounding) <= 43, (o, d, c, r)
+        worst_rounding = max(worst_rounding, abs(rounding))
         worst_low = gap if worst_low is None else min(worst_low, gap)
         worst_high = gap if worst_high is None else max(worst_high, gap)
         if disc >= 0:
@@ -89,7 +95,7 @@ def test_filter_never_drops_a_sphere_the_exact_discriminant_accepts(oracle):
         if disc >= 0 and not (h < 0 and cc > 0):
             assert f["kept"]
     print(f"lowered - exact discriminant (per unit direction) in units of u*S^2: min {float(worst_low):.2f}, max {float(worst_high):.2f}; "
-          f"error of the centre's parameter: at most {worst_h:.2f} u*S; kept {kept} of {total}")
+          f"rounding alone at most {float(worst_rounding):.2f} (bound 43); error of the centre's parameter: at most {worst_h:.2f} u*S (bound 12); kept {kept} of {total}")
     assert worst_low > 24
 
 
