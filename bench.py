@@ -7,21 +7,28 @@ A step is one full render of the workload: every pixel, every sample, through th
 (rt_render_accumulate + rt_finalize), with the world and camera already resident in HBM.
 
 N=1: the book's final random-spheres scene, 1200x675, 500 spp, depth 50 (the configuration the
-metric is quoted on).  The timed mode is `--precision` (default mixed: the reference's f64 image
-bit for bit, f32 scan as a conservative filter); the other arithmetic modes are timed beside it
-(`modes` in the output) unless --single-mode.
+metric is quoted on).  The timed mode is `--precision` (default mixed-fixed: the reference's f64
+paths bit for bit behind the f32 filter scan, sample colours added exactly in fixed point; the
+frame is checked in the run against the f64 kernel -- 1e-12 relative, every 8-bit pixel equal);
+the other arithmetic modes are timed beside it (`modes` in the output) unless --single-mode.
 
 N>1 (one process per GPU, launched by torch.distributed.run): ONE FIXED frame -- the final scene
 at 3840x2160, 500 spp -- shared by the ranks (strong scaling).  `--partition rows` (default) deals
 8-row strips over the ranks and rank 0 gathers each rank's own rows; `--partition samples` splits
-the 500 samples over the ranks and sums the exact Q32.32 accumulators with an RCCL all-reduce
-(f32 mode only: f64 sums are order-dependent).  `--weak` restores weak scaling (sample partition,
-500 spp per rank, a 500*N-spp frame).
+the 500 samples over the ranks and sums the exact fixed-point accumulators with an RCCL all-reduce
+(f32 and mixed-fixed: integer sums; f64 sums are order-dependent).  `--weak` restores weak scaling
+(sample partition, 500 spp per rank, a 500*N-spp frame).  The N>1 line carries, per rank, the
+render-kernel time, the segments traced, the time of the whole render part and of the collective
+part of a step, and the imbalance, so that a scaling curve can be read without a second run.
+
+`--config 3|4|5` selects one of the named configurations: 3 = final scene 1200x675 x 500 spp,
+4 = final scene 3840x2160 x 500 spp, 5 = 10 000-sphere stress scene 1920x1080 x 256 spp.
 
 Prints one JSON line on rank 0 with the driver's fields plus `roofline` (FP32 VALU) and
 `cpu_baseline` (the f64 CPU restatement of the reference timed on this host's cores).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -32,17 +39,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_TEST = 17                 # algorithmic FLOP per ray/sphere test (3 sub, 5+5 dot products, -r^2, h*h-a*c)
+F_TEST_EXECUTED = 14        # what the filter scan executes per test: one multiply and six fused multiply-adds (+ the shared gate)
 PEAK_FP32_TFLOPS = 157.3    # MI355X vector FP32 peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 GATHER_PEAK_G = 917.8       # --fetch bvh: divergent 16-byte gathers per ns from an L2-resident table, measured by tools/gather_peak
-PMC_SUMMARY = os.path.join("profiles", "round2_pmc_counters.json")
+PMC_SUMMARIES = [os.path.join("profiles", "round3_pmc_counters.json"), os.path.join("profiles", "round2_pmc_counters.json")]
+KERNEL_SOURCES = ["rt_kernel.hip", "rt_kernel.h", "rt_api.cpp"]
 
 # what each arithmetic mode computes in and which of the spec's parity criteria it meets on the headline frame
 MODES = {
     "f32": dict(dtype="f32", parity="f32 paths: 81 % of pixels within 1e-4 and 98 % of 8-bit pixels equal to the f64 reference on this frame "
                                     "(tests assert the floors); meets 1e-4 / 99.9 % on the three-material configuration only"),
     "mixed": dict(dtype="f64 (f32 candidate filter)", parity="bitwise the f64 reference arithmetic (every pixel; 1e-4 and 99.9 % criteria met)"),
+    "mixed-fixed": dict(dtype="f64 (f32 candidate filter)", parity="f64 reference paths bit for bit, sample colours summed exactly in Q32.64 instead of sequentially in f64: "
+                                                                    "within 1e-12 relative of the f64 reference per linear pixel, every 8-bit pixel equal (checked in the run)"),
     "f64": dict(dtype="f64", parity="bitwise the f64 reference arithmetic (every pixel; 1e-4 and 99.9 % criteria met)"),
 }
+CONFIGS = {3: ("final", 1200, 500), 4: ("final", 3840, 500), 5: ("stress", 1920, 256)}
+KERNEL_TAGS = {"f32": "render_kernel<float, fma, scalar fetch, queue>",
+               "mixed": "render_kernel<double, f32 filter, scalar fetch, queue> + order_sum_kernel",
+               "mixed-fixed": "render_kernel<double, f32 filter, scalar fetch, queue, Q32.64 atomics>",
+               "f64": "render_kernel<double, literal, scalar fetch> + reduce_kernel"}
 
 
 def parse():
@@ -50,10 +66,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 3, 4, 5], help="a named configuration: scene, width and spp in one flag")
     ap.add_argument("--width", type=int, default=0, help="image width (default: 1200 at N=1, 3840 at N>1)")
-    ap.add_argument("--spp", type=int, default=500)
-    ap.add_argument("--scene", default="final", choices=["final", "dev", "stress"])
-    ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: 500; 256 for the stress scene)")
+    ap.add_argument("--scene", default=None, choices=["final", "dev", "stress"])
+    ap.add_argument("--precision", default="mixed-fixed", choices=["f32", "mixed", "mixed-fixed", "f64"])
     ap.add_argument("--single-mode", action="store_true", help="N=1: do not time the other arithmetic modes beside --precision")
     ap.add_argument("--partition", default="rows", choices=["samples", "rows"])
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling (sample partition, --spp per rank)")
@@ -64,27 +81,62 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.config:
+        scene, width, spp = CONFIGS[args.config]
+        args.scene = args.scene or scene
+        args.width = args.width or width
+        args.spp = args.spp or spp
+    args.scene = args.scene or "final"
     if args.width == 0:
-        args.width = 1200 if args.gpus == 1 else 3840
+        args.width = 1920 if args.scene == "stress" else (1200 if args.gpus == 1 else 3840)
+    if args.spp == 0:
+        args.spp = 256 if args.scene == "stress" else 500
     if args.weak:
         args.partition = "samples"
     if args.fetch.startswith("bvh") and args.precision == "f64":
-        ap.error("--fetch bvh serves --precision f32 and mixed (the f64 image at the hierarchy's speed)")
-    if args.partition == "samples" and args.gpus > 1 and args.precision != "f32":
-        ap.error("--partition samples adds accumulators across ranks, which is exact only for --precision f32 (Q32.32); use --partition rows")
+        ap.error("--fetch bvh serves --precision f32, mixed and mixed-fixed (the f64 paths at the hierarchy's speed)")
+    if args.partition == "samples" and args.gpus > 1 and args.precision not in ("f32", "mixed-fixed"):
+        ap.error("--partition samples adds accumulators across ranks, which is exact only for the fixed-point sums of --precision f32 (Q32.32) "
+                 "and mixed-fixed (Q32.64); use --partition rows")
     return args
 
 
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(args):
-    """HBM-side bytes of one render launch of the default workload from the committed rocprofv3
-    FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile.sh); not measured in this run."""
-    if (args.scene, args.width, args.spp, args.gpus) != ("final", 1200, 500, 1):
-        return None
-    try:
-        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
-            return float(json.load(f)["TRAFFIC_BYTES_500SPP"][args.precision])
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    """HBM-side bytes of one render launch of the default workload from the committed rocprofv3 FETCH_SIZE /
+    WRITE_SIZE passes over this same command (tools/profile.sh); not measured in this run.  Returns (bytes,
+    source): the source says `stale` when the kernels have changed since the passes were taken."""
+    if (args.scene, args.width, args.spp, args.gpus) != ("final", 1200, 500, 1) or args.fetch.startswith("bvh"):
+        return None, "none: the committed rocprofv3 passes cover the default single-GPU workload only"
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, name)) as f:
+                d = json.load(f)
+            value = float(d["TRAFFIC_BYTES_500SPP"][args.precision])
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+        recorded = d.get("kernel_source_sha16")
+        state = "current" if recorded == kernel_source_hash() else ("stale" if recorded else "stale (taken before source hashes were recorded)")
+        return value, f"{name}, {state}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not measured in this run"
+    return None, "none: no committed rocprofv3 pass covers this precision"
+
+
+def traffic_model(mode, samples, w, h, n_spheres):
+    """memory-side bytes of one frame's kernels, from what they issue (the model the PMC figure is read against)"""
+    if mode == "mixed":       # every sample colour staged (24 B written), read once by the ordered sum, accumulators written
+        return samples * 24 * 2 + w * h * 24 + n_spheres * 16
+    if mode == "mixed-fixed":  # six 8-byte atomic adds per sample, accumulators cleared once
+        return samples * 6 * 8 + w * h * 48 + n_spheres * 16
+    if mode == "f32":         # three 8-byte atomic adds per sample
+        return samples * 3 * 8 + w * h * 24 + n_spheres * 16
+    return w * h * 24 * 2 + n_spheres * 32   # f64: per-lane register sums, stored once per chunk
 
 
 def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
@@ -94,25 +146,37 @@ def cpu_baseline(rt, cam, sph, mat, width, height, seconds):
     import oracle_lib
     o = oracle_lib.Oracle()
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    # the time of a 1-spp frame from a band of rows in the middle (a whole 1-spp frame of a 10 000-sphere world takes minutes)
+    band = max(1, min(height, 16))
+    v0 = (height - band) // 2
     t0 = time.perf_counter()
-    o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=cores)
-    est_full_1spp = max(time.perf_counter() - t0, 1e-4)  # the whole frame at 1 spp
-    spp = max(1, min(512, int(seconds / est_full_1spp)))
+    o.render_region(width, height, (0, v0, width, v0 + band), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=cores)
+    est_full_1spp = max(time.perf_counter() - t0, 1e-4) * height / band
+    if est_full_1spp <= seconds:
+        rows, spp = height, max(1, min(512, int(seconds / est_full_1spp)))
+        what = f"full {width}x{height} frame at {spp} spp"
+        region = (0, 0, width, height)
+    else:  # every k-th row pair is not expressible as a rect: a centred band of whole rows at 1 spp
+        rows, spp = max(band, int(height * seconds / est_full_1spp)), 1
+        y0 = (height - rows) // 2
+        what = f"rows [{y0}, {y0 + rows}) of the {width}x{height} frame at 1 spp"
+        region = (0, y0, width, y0 + rows)
     t0 = time.perf_counter()
-    r = o.render_region(width, height, (0, 0, width, height), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=spp, threads=cores)
+    r = o.render_region(width, height, region, cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=spp, threads=cores)
     dt = time.perf_counter() - t0
-    samples = width * height * spp
-    # one thread, the reference's default (RENDER_MULTITHREADED = false, main.odin:14): every 2nd row of one 1-spp frame
-    rows = list(range(0, height, 2))
+    samples = width * rows * spp
+    # one thread, the reference's default (RENDER_MULTITHREADED = false, main.odin:14): rows spread over the frame at 1 spp
+    n1 = max(1, min(height // 2, int(rows * spp / cores / 2)))
+    picks = [int(k * height / n1) for k in range(n1)]
     t0 = time.perf_counter()
-    for v in rows:
+    for v in picks:
         o.render_region(width, height, (0, v, width, v + 1), cam, sph, mat, precision=rt.PRECISION_F64, seed=1, sample_count=1, threads=1)
     dt1 = time.perf_counter() - t0
     return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"full {width}x{height} frame at {spp} spp ({samples} samples, {dt:.1f} s), f64, {cores} threads over rows",
+            "sample": f"{what} ({samples} samples, {dt:.1f} s), f64, {cores} threads over rows",
             "segments_per_sample": float(r["stats"][0]) / samples,
-            "single_thread": {"value": width * len(rows) / dt1 / 1e6, "unit": "Msamples/s", "cores": 1,
-                              "sample": f"every 2nd row of the frame at 1 spp ({width * len(rows)} samples, {dt1:.1f} s)"}}
+            "single_thread": {"value": width * len(picks) / dt1 / 1e6, "unit": "Msamples/s", "cores": 1,
+                              "sample": f"{len(picks)} rows spread over the frame at 1 spp ({width * len(picks)} samples, {dt1:.1f} s)"}}
 
 
 class HostStaged:
@@ -138,6 +202,12 @@ class HostStaged:
 
     def barrier(self):
         self._d.barrier()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_backend(self):
+        return self._d.get_backend()
 
     def destroy_process_group(self):
         self._d.destroy_process_group()
@@ -183,7 +253,7 @@ def main():
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
     fetch = {"auto": rt.FETCH_AUTO, "scalar": rt.FETCH_SCALAR, "lds": rt.FETCH_LDS, "bvh": rt.FETCH_BVH, "bvh-global": rt.FETCH_BVH_GLOBAL}[args.fetch]
-    precisions = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "f64": rt.PRECISION_F64}
+    precisions = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "mixed-fixed": rt.PRECISION_MIXED_FIXED, "f64": rt.PRECISION_F64}
 
     world = rt.World(sph, mat, device=local_rank)
     image = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
@@ -203,8 +273,11 @@ def main():
     def run_mode(mode, steps, warmup):
         """time `steps` frames in arithmetic mode `mode`; returns the measurements and the buffer holding rank 0's frame"""
         precision = precisions[mode]
-        # Q32.32 sums (exact, so an all-reduce over ranks is order-independent) or f64 sums in sample order
-        accum = torch.zeros(h, w, 3, dtype=torch.int64 if mode == "f32" else torch.float64, device=dev)
+        # fixed-point sums (exact, so an all-reduce over ranks is order-independent; Q32.64: two words per channel) or f64 sums in sample order
+        if mode == "mixed-fixed":
+            accum = torch.zeros(h, w, 3, 2, dtype=torch.int64, device=dev)
+        else:
+            accum = torch.zeros(h, w, 3, dtype=torch.int64 if mode == "f32" else torch.float64, device=dev)
         collect = {"stats": False}
 
         def trace(buf, **kw):
@@ -214,9 +287,11 @@ def main():
         def finish(buf, img, total_samples, **kw):
             world.finalize(buf.data_ptr(), w, h, total_samples, img.data_ptr(), precision=precision, stream=stream, **kw)
 
-        def step(collect_stats=False):
+        timers = multi_gpu.StepTimers() if world_size > 1 else None
+
+        def step(collect_stats=False, timed=False):
             collect["stats"] = collect_stats
-            return multi_gpu.render_step(plan, dist, accum, image, gathered, trace, finish, row_gather)
+            return multi_gpu.render_step(plan, dist, accum, image, gathered, trace, finish, row_gather, timers=timers if timed else None)
 
         # one counted pass: exact segment count of this rank's share of a step
         stats.zero_()
@@ -231,18 +306,28 @@ def main():
         t0 = time.perf_counter()
         knl = []
         for _ in range(steps):
-            frame = step()
+            frame = step(timed=True)
             # device time of this step's render kernels: HIP events recorded around them on the launch stream
             knl.append(world.last_kernel_ns())
         fence()
         elapsed = time.perf_counter() - t0
+        m["kernel_s"] = sum(knl) / len(knl) * 1e-9
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        seg_t = torch.tensor([m["segments"], m["samples_rank"]], dtype=torch.int64, device=dev)
         if world_size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
+            # every rank's own measurements, gathered as one row each of a table that is summed over the ranks
+            render_ms, collective_ms = timers.means_ms()
+            table = torch.zeros(world_size, 6, dtype=torch.float64, device=dev)
+            table[rank] = torch.tensor([m["kernel_s"] * 1e3, render_ms, collective_ms, m["segments"], m["samples_rank"], elapsed * 1e3 / steps], dtype=torch.float64)
+            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+            rows = table.cpu().tolist()
+            m["per_rank"] = {"render_kernel_ms": [r[0] for r in rows], "render_part_ms": [r[1] for r in rows], "collective_part_ms": [r[2] for r in rows],
+                             "segments": [int(r[3]) for r in rows], "samples": [int(r[4]) for r in rows], "step_ms": [r[5] for r in rows]}
+            m["segments_all"] = sum(int(r[3]) for r in rows)
+            m["samples_all"] = sum(int(r[4]) for r in rows)
+        else:
+            m["segments_all"], m["samples_all"] = m["segments"], m["samples_rank"]
         m["elapsed"] = float(t.item())
-        m["kernel_s"] = sum(knl) / len(knl) * 1e-9
         m["steps"] = steps
         m["value"] = w * h * total_spp * steps / m["elapsed"] / 1e6
         # list scan: every segment tests every sphere; hierarchy: the tests the traversal carried out (counted by the kernel)
@@ -252,28 +337,45 @@ def main():
 
     def verify(mode, frame):
         """the timed frame against ONE rt_render_region call over all total_spp samples on rank 0's GPU: bitwise.
-        The mixed mode is checked against the f64 kernel (the reference's arithmetic as written) rather than against itself."""
+        The mixed mode is checked against the f64 kernel (the reference's arithmetic as written) rather than against
+        itself; the fixed-point mixed mode against both -- bitwise its own single call, and the f64 kernel to
+        1e-12 relative per linear pixel with every 8-bit pixel equal."""
         import numpy as np
         cs.samples_per_pixel = total_spp
-        whole = np.zeros((h, w, 3))
+        cam_all = rt.calculate_camera_render_data(cs)
+        cs.samples_per_pixel = args.spp
+        got = frame.cpu().numpy()
+
+        def one_call(against, chunks):
+            whole = np.zeros((h, w, 3))
+            rt.render_region(whole, (0, 0, w, h), cam_all, sph, mat, seed=1, device=local_rank, precision=precisions[against],
+                             sphere_fetch=fetch if against == mode else rt.FETCH_AUTO, sample_chunks=chunks)
+            return whole
+
+        if mode == "mixed-fixed":
+            same = bool(np.array_equal(got, one_call("mixed-fixed", 0)))
+            ref = one_call("f64", 1)
+            lin, lin_ref = got * got, ref * ref      # gamma 2: the linear values up to one rounding
+            lit = lin_ref > 1e-7
+            rel = float(np.max(np.abs(lin[lit] - lin_ref[lit]) / lin_ref[lit])) if lit.any() else 0.0
+            eq8 = float(np.mean(rt.quantize_rgb8(got) == rt.quantize_rgb8(ref)))
+            ok = same and rel <= 1e-12 and eq8 == 1.0 and bool(np.all(np.abs(lin[~lit] - lin_ref[~lit]) <= 1e-15))
+            return ok, (f"rt_render_region: mixed-fixed kernel, one call, bitwise = {same}; f64 kernel (reference arithmetic, sequential sums): "
+                        f"max relative difference per linear pixel {rel:.2e}, identical 8-bit values {100 * eq8:.4f} %")
         against = "f64" if mode == "mixed" else mode
         # f64 sums follow the chunking: one chunk = strict sample order (what the mixed mode produces); an f64 run is re-rendered with its own chunking
         chunks = 1 if mode == "mixed" else args.chunks
-        rt.render_region(whole, (0, 0, w, h), rt.calculate_camera_render_data(cs), sph, mat, seed=1, device=local_rank,
-                         precision=precisions[against], sphere_fetch=fetch if against == mode else rt.FETCH_AUTO, sample_chunks=chunks)
-        cs.samples_per_pixel = args.spp
-        return bool(np.array_equal(frame.cpu().numpy(), whole)), f"rt_render_region, {against} kernel, one call, bitwise"
+        return bool(np.array_equal(got, one_call(against, chunks))), f"rt_render_region, {against} kernel, one call, bitwise"
 
     m, frame = run_mode(args.precision, args.steps, args.warmup)
     out = None
+    samples_frame = w * h * total_spp
     if rank == 0:
-        tag = {"f32": "render_kernel<float, fma, scalar fetch, queue>", "mixed": "render_kernel<double, f32 filter, scalar fetch, queue> + order_sum_kernel",
-               "f64": "render_kernel<double, literal, scalar fetch> + reduce_kernel"}[args.precision]
         partition = "single GPU"
         if world_size > 1:
             partition = (f"8-row strips dealt over the ranks, gather of each rank's rows to rank 0 ({backend})" if args.partition == "rows"
-                         else f"sample split, all-reduce of the Q32.32 accumulators ({backend})")
-        traffic = measured_traffic(args) if not args.fetch.startswith("bvh") else None
+                         else f"sample split, all-reduce of the fixed-point accumulators ({backend})")
+        traffic, traffic_source = measured_traffic(args)
         out = {
             "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak" if (args.scene, w, total_spp) == ("final", 1200, 500)
                       else f"Msamples/sec (whole node), {args.scene} scene {w}x{h} {total_spp}spp; % FP32 VALU peak",
@@ -284,44 +386,63 @@ def main():
                        "precision": args.precision, "parity": MODES[args.precision]["parity"], "partition": partition,
                        "total_spp": total_spp, "sphere_fetch": args.fetch, "rng": "counter, deterministic, seed 1"},
             "pct_fp32_peak": 100.0 * m["achieved"] / PEAK_FP32_TFLOPS,
+            "pct_fp32_peak_executed": 100.0 * m["achieved"] * F_TEST_EXECUTED / F_TEST / PEAK_FP32_TFLOPS,
             "segments_per_sample": m["segments"] / max(1, m["samples_rank"]),
             "lane_utilization": m["segments"] / max(1, 64 * m["wave_iters"]),
             "roofline": {"bound": "valu_fp32", "achieved": m["achieved"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": m["achieved"] / PEAK_FP32_TFLOPS,
-                         "traffic": traffic,
-                         "traffic_source": f"{PMC_SUMMARY} (rocprofv3 --pmc passes over this command; not measured in this run)" if traffic is not None
-                                           else "none: the committed rocprofv3 passes cover the default single-GPU workload only",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_model": traffic_model(args.precision, samples_frame // world_size if args.partition == "samples" else m["samples_rank"], w, h, len(sph)),
                          "algorithmic_bytes": w * h * 24 + len(sph) * 16,
-                         "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator/staging stores and atomics are a few % of HBM bandwidth",
-                         "kernel": tag, "kernel_ms": m["kernel_s"] * 1e3, "flop_per_test": F_TEST, "sphere_tests_per_launch": m["tests_rank"]},
+                         "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator atomics or staging stores are a few % of HBM bandwidth. "
+                                         "traffic_model = bytes the kernels of one launch issue (atomics 8 B each, staged colours written and read once)",
+                         "kernel": KERNEL_TAGS[args.precision], "kernel_ms": m["kernel_s"] * 1e3, "flop_per_test": F_TEST,
+                         "executed_flop_per_test": F_TEST_EXECUTED, "frac_executed": m["achieved"] * F_TEST_EXECUTED / F_TEST / PEAK_FP32_TFLOPS,
+                         "frac_note": "frac = algorithmic FLOP (17 per ray/sphere test) over peak; the filter scan executes 14 per test, so frac can reach 1.21 and "
+                                      "frac_executed is the share of the pipe's issue capacity the scan's arithmetic itself takes",
+                         "sphere_tests_per_launch": m["tests_rank"], "kernel_source_sha16": kernel_source_hash()},
         }
+        if world_size > 1:
+            pr = m["per_rank"]
+            mean_k = sum(pr["render_kernel_ms"]) / world_size
+            mean_s = sum(pr["segments"]) / world_size
+            out["ranks"] = {"world_size_reported": dist.get_world_size(), "backend": dist.get_backend(), **pr,
+                            "imbalance_kernel_ms": max(pr["render_kernel_ms"]) / max(mean_k, 1e-9) - 1.0,
+                            "imbalance_segments": max(pr["segments"]) / max(mean_s, 1e-9) - 1.0,
+                            "note": "per rank, means over the timed steps: render_kernel_ms = HIP events around the render kernels; render_part_ms = trace + finalise "
+                                    "up to the collective; collective_part_ms = gather + scatter of rows (or the all-reduce + finalise) as seen on the rank's stream, "
+                                    "which includes waiting for the slowest rank; roofline figures are rank 0's"}
         if args.fetch.startswith("bvh"):
             # The traversal is bound by the vector L1's rate of serving per-lane 16-byte gathers that fall into different cache
             # lines: one per box tested, two per sphere tested.  Peak: the L2-resident rate tools/gather_peak measures on this chip.
             gathers = m["bvh_nodes"] + 2 * m["bvh_tests"]
             out["bvh"] = {"boxes_per_segment": m["bvh_nodes"] / max(1, m["segments"]), "sphere_tests_per_segment": m["bvh_tests"] / max(1, m["segments"])}
             out["roofline"] = {"bound": "vl1d_gather", "achieved": gathers / m["kernel_s"] / 1e9, "peak": GATHER_PEAK_G, "unit": "Ggather/s",
-                               "frac": gathers / m["kernel_s"] / 1e9 / GATHER_PEAK_G, "traffic": None, "kernel": "render_kernel<float, fma, bvh>" if args.precision == "f32" else "render_kernel<double, f32 filter, bvh> + order_sum_kernel",
+                               "frac": gathers / m["kernel_s"] / 1e9 / GATHER_PEAK_G, "traffic": None,
+                               "kernel": "render_kernel<float, fma, bvh>" if args.precision == "f32" else "render_kernel<double, f32 filter, bvh>",
                                "kernel_ms": m["kernel_s"] * 1e3, "gathers_per_launch": gathers, "sphere_tests_per_launch": m["bvh_tests"]}
             out["pct_fp32_peak"] = None
+            out["pct_fp32_peak_executed"] = None
         if not args.no_verify:
             out["verified"], out["verified_against"] = verify(args.precision, frame)
     if world_size == 1 and not args.single_mode and not args.fetch.startswith("bvh"):
         # the other arithmetic modes on the same workload, fewer steps: what each costs and which parity criteria it meets
         out["modes"] = {args.precision: {"value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": m["kernel_s"] * 1e3,
                                          "pct_fp32_peak": out["pct_fp32_peak"], "dtype": out["dtype"], "parity": MODES[args.precision]["parity"],
-                                         "verified": out.get("verified")}}
-        for mode in ("f32", "mixed", "f64"):
+                                         "verified": out.get("verified"), "traffic_model": out["roofline"]["traffic_model"]}}
+        for mode in ("mixed-fixed", "mixed", "f32", "f64"):
             if mode == args.precision:
                 continue
             steps = max(1, min(args.steps, 3 if mode != "f64" else 2))
             mm, fr = run_mode(mode, steps, 1 if args.warmup > 0 else 0)
             entry = {"value": mm["value"], "ms_per_step": mm["elapsed"] / steps * 1e3, "kernel_ms": mm["kernel_s"] * 1e3,
-                     "pct_fp32_peak": 100.0 * mm["achieved"] / PEAK_FP32_TFLOPS, "dtype": MODES[mode]["dtype"], "parity": MODES[mode]["parity"], "steps": steps}
-            if not args.no_verify and mode == "f32":
+                     "pct_fp32_peak": 100.0 * mm["achieved"] / PEAK_FP32_TFLOPS, "dtype": MODES[mode]["dtype"], "parity": MODES[mode]["parity"], "steps": steps,
+                     "traffic_model": traffic_model(mode, samples_frame, w, h, len(sph))}
+            if not args.no_verify and mode != "f64":
                 entry["verified"], _ = verify(mode, fr)
             out["modes"][mode] = entry
     if rank == 0:
-        if not args.no_cpu_baseline and world_size == 1:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, after the timed region (at N>1 the other ranks wait at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(rt, cam, sph, mat, w, h, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     world.close()

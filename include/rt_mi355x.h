@@ -109,7 +109,17 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
                                       and every sphere it keeps goes through ray_sphere_intersection as written
                                       (main.odin:245-261) in f64; hit record, scattering and colour are f64.
                                       Worlds outside 2^-20 <= |r|, |c| + |r| <= 2^20 are traced by the
-                                      RT_PRECISION_F64 kernel instead (same image).  RT_FETCH_AUTO / _SCALAR.    */
+                                      RT_PRECISION_F64 kernel instead (same image).  RT_FETCH_AUTO / _SCALAR.
+                                      THE DEFAULT (rt_options_default, opts == NULL).                             */
+#define RT_PRECISION_MIXED_FIXED 4 /* the paths of RT_PRECISION_MIXED (f64, bit for bit the reference's), with
+                                      `pixel_color += sample_color` (main.odin:575) carried out in fixed point: each
+                                      f64 sample colour is truncated to a multiple of 2^-64 and added as an integer
+                                      (two 64-bit words per channel, atomic adds), so the sum is exact, does not
+                                      depend on the order in which lanes, waves, calls or GPUs finish samples, and
+                                      needs no buffer beyond the accumulators; the mean is that sum rounded to f64
+                                      ONCE, times 1/spp.  It differs from the reference's sequential f64 sum by that
+                                      sum's own rounding (a few 2^-53 relative): not bitwise the RT_PRECISION_F64
+                                      image, but within 1e-12 relative of it per linear pixel.                   */
 
 /* how the closest hit (main.odin:536-546) is found */
 #define RT_FETCH_AUTO 0   /* = RT_FETCH_SCALAR                                                     */
@@ -125,6 +135,12 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 
 #define RT_RNG_STOCHASTIC 0    /* seed is mixed with a per-process call counter and the clock */
 #define RT_RNG_DETERMINISTIC 1 /* the counter RNG is keyed by `seed` alone: same inputs, same image */
+
+/* rt_options.flags */
+#define RT_FLAG_PRINT_PROGRESS 1 /* the $print_progress parameter of render_region (main.odin:510): the call prints the
+                                    reference's closing "Done." line to stderr (main.odin:590).  The per-scanline
+                                    "Scanlines remaining" counter (main.odin:514) has no counterpart: the GPU does not
+                                    render scanline by scanline                                                      */
 
 /* indices into the optional stats array */
 #define RT_STAT_SEGMENTS 0     /* ray segments traced = executed iterations of the bounce loop main.odin:535 */
@@ -148,6 +164,8 @@ typedef struct {
                               RT_MI355X_WRAP_DEVICES=1 in the environment the ordinals wrap
                               around the visible GPUs (a testing aid for boxes with fewer)   */
     int32_t sample_chunks; /* split samples_per_pixel over this many waves per tile; 0 = auto */
+    int32_t flags;         /* RT_FLAG_*                                                        */
+    int32_t reserved;      /* 0                                                                */
     rt_v3 *linear_out;     /* optional, width*height: pre-gamma sample means of region pixels  */
     uint64_t *stats;       /* optional, RT_STATS_COUNT counters for this call                  */
 } rt_options;
@@ -173,7 +191,8 @@ void rt_options_default(rt_options *opts);
  * image_data[u + v * width].  Pixels outside `region` are not touched.
  * Host pointers in, host pointers out; synchronous; safe to call from several
  * threads (calls are serialised per device).
- * opts may be NULL (f32, deterministic, seed 0, current device).
+ * opts may be NULL (RT_PRECISION_MIXED -- the image of the reference's f64 arithmetic --, deterministic,
+ * seed 0, current device: what rt_options_default sets).
  */
 int32_t rt_render_region(rt_v3 *image_data, int64_t width, int64_t height, rt_rect region,
                          const rt_camera_render_data *cam,

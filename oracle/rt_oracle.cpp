@@ -581,6 +581,7 @@ struct render_args {
     double *image, *linear, *accum;
     uint64_t *stats;
     int32_t threads;
+    uint64_t *words = nullptr; /* RT_PRECISION_MIXED_FIXED: optional width*height*3*2 accumulator words {a, b} */
 };
 
 /* Q32.32 fixed point of a non-negative f32, truncated below 2^-32 (NaN and negatives -> 0):
@@ -598,6 +599,33 @@ inline double q32_32_to_f64(uint64_t v) {
     return static_cast<double>(static_cast<uint32_t>(v >> 32)) * 4294967296.0 + static_cast<double>(static_cast<uint32_t>(v));
 }
 
+/* Q32.64 fixed point of a non-negative f64 as two words (the accumulator format of RT_PRECISION_MIXED_FIXED):
+ * a = floor(x * 2^32), b = the next 32 bits; truncated below 2^-64, NaN and negatives -> 0, x >= 2^32 saturates. */
+inline void to_q32_64(double x, uint64_t &a, uint64_t &b) {
+    a = 0; b = 0;
+    if (!(x > 0.0)) return;
+    if (x >= 4294967296.0) { a = ~0ull; b = 0xFFFFFFFFull; return; }
+    const uint32_t hi = static_cast<uint32_t>(x);
+    const double t1 = (x - static_cast<double>(hi)) * 4294967296.0;
+    const uint32_t mid = static_cast<uint32_t>(t1);
+    const double t2 = (t1 - static_cast<double>(mid)) * 4294967296.0;
+    a = (static_cast<uint64_t>(hi) << 32) | mid;
+    b = static_cast<uint64_t>(static_cast<uint32_t>(t2));
+}
+/* a * 2^-32 + b * 2^-64 rounded to f64 once: the 128-bit integer a * 2^32 + b through unsigned __int128, whose
+ * conversion would be the compiler's business; here its top 64 bits with a sticky lowest bit, converted (one
+ * rounding) and scaled by a power of two. */
+inline double q32_64_to_f64(uint64_t a, uint64_t b) {
+    const unsigned __int128 t = (static_cast<unsigned __int128>(a) << 32) + b;
+    const uint64_t hi = static_cast<uint64_t>(t >> 64), lo = static_cast<uint64_t>(t);
+    if (hi == 0) return static_cast<double>(lo) * 5.421010862427522e-20; /* 2^-64 */
+    const int shift = __builtin_clzll(hi);
+    const unsigned __int128 n = t << shift;
+    uint64_t top = static_cast<uint64_t>(n >> 64);
+    if (static_cast<uint64_t>(n) != 0) top |= 1;
+    return std::ldexp(static_cast<double>(top), -shift);
+}
+
 /* render_region  main.odin:510-591 over global sample indices
  * [sample_begin, sample_begin + sample_count).
  * QACC = false: pixel_color is a Real sum in sample order, the mean and the gamma square root
@@ -606,7 +634,7 @@ inline double q32_32_to_f64(uint64_t v) {
  *   order in which the GPU combines its per-chunk partial sums).
  * QACC = true (f32 throughput arithmetic): each f32 sample colour is converted to Q32.32 and
  *   summed exactly in u64; mean and square root are taken in f64. */
-template <class Real, bool FMA, bool QACC, bool MIXED = false> void render(const render_args &A) {
+template <class Real, bool FMA, bool QACC, bool MIXED = false, bool FIXED = false> void render(const render_args &A) {
     scene_t<Real> sc(A.cam, A.spheres, A.n_spheres, A.materials, A.n_materials);
     const seed_keys keys = keys_from_seed(A.seed);
     const Real contribution = Real(1) / static_cast<Real>(A.sample_count); /* main.odin:512 */
@@ -632,6 +660,25 @@ template <class Real, bool FMA, bool QACC, bool MIXED = false> void render(const
                     for (int k = 0; k < 3; ++k) {
                         const double mean = (q32_32_to_f64(q[k]) * (1.0 / 4294967296.0)) * contribution64;
                         if (A.accum) A.accum[index * 3 + k] = static_cast<double>(q[k]); /* exact below 2^53 */
+                        if (A.linear) A.linear[index * 3 + k] = mean;
+                        if (A.image) A.image[index * 3 + k] = std::sqrt(mean);
+                    }
+                    continue;
+                }
+                if (FIXED) {
+                    /* RT_PRECISION_MIXED_FIXED: the mixed mode's f64 sample colours, added exactly in Q32.64; the sum
+                     * is rounded to f64 once, then the mean and the square root as main.odin:577-583 */
+                    uint64_t qa[3] = {0, 0, 0}, qb[3] = {0, 0, 0};
+                    for (int64_t s = 0; s < A.sample_count; ++s) {
+                        vec3<Real> c = trace_sample<Real, FMA, MIXED>(sc, keys, u, v, A.width, static_cast<uint32_t>(A.sample_begin + s), &segments, &fc);
+                        const double ch[3] = {static_cast<double>(c.x), static_cast<double>(c.y), static_cast<double>(c.z)};
+                        for (int k = 0; k < 3; ++k) { uint64_t a, b; to_q32_64(ch[k], a, b); qa[k] += a; qb[k] += b; }
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double sum = q32_64_to_f64(qa[k], qb[k]);
+                        const double mean = sum * contribution64;
+                        if (A.accum) A.accum[index * 3 + k] = sum;
+                        if (A.words) { A.words[(index * 3 + k) * 2] = qa[k]; A.words[(index * 3 + k) * 2 + 1] = qb[k]; }
                         if (A.linear) A.linear[index * 3 + k] = mean;
                         if (A.image) A.image[index * 3 + k] = std::sqrt(mean);
                     }
@@ -705,8 +752,21 @@ int32_t oracle_render_region(int32_t precision, double *image, double *linear, d
     case RT_PRECISION_F32: render<float, true, true>(A); return 0;
     case RT_PRECISION_F32_LITERAL: render<float, false, false>(A); return 0;
     case RT_PRECISION_MIXED: render<double, false, false, true>(A); return 0;
+    case RT_PRECISION_MIXED_FIXED: render<double, false, false, true, true>(A); return 0;
     default: return -1;
     }
+}
+
+/* RT_PRECISION_MIXED_FIXED with the accumulator words themselves: words[(index * 3 + channel) * 2 + {0, 1}] = the sums of
+ * the samples' a and b words (units of 2^-32 and of 2^-64), what the GPU's accumulators hold up to carries between the two. */
+int32_t oracle_render_fixed_words(uint64_t *words, int64_t width, int64_t height, rt_rect region, const rt_camera_render_data *cam,
+                                  const rt_sphere *spheres, int64_t n_spheres, const rt_material *materials, int64_t n_materials,
+                                  uint64_t seed, int64_t sample_begin, int64_t sample_count, int32_t threads) {
+    render_args A{width, height, region, cam, spheres, n_spheres, materials, n_materials, seed,
+                  sample_begin, sample_count, 1, nullptr, nullptr, nullptr, nullptr, threads};
+    A.words = words;
+    render<double, false, false, true, true>(A);
+    return 0;
 }
 
 /* The mixed mode's filter for one ray and one sphere, with its intermediate values:

@@ -26,7 +26,10 @@ RT_ERR_DEVICE = -3
 RT_ERR_UNSUPPORTED = -4
 RT_ERR_BUFFER_TOO_SMALL = -5
 LAMBERTIAN, METALLIC, DIELECTRIC = 0, 1, 2
-PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL, PRECISION_MIXED = 0, 1, 2, 3
+PRECISION_F32, PRECISION_F64, PRECISION_F32_LITERAL, PRECISION_MIXED, PRECISION_MIXED_FIXED = 0, 1, 2, 3, 4
+FLAG_PRINT_PROGRESS = 1
+#: bytes per accumulator element (three elements per pixel) of rt_render_accumulate, by precision
+ACCUM_ELEMENT_BYTES = {PRECISION_F32: 8, PRECISION_F64: 8, PRECISION_F32_LITERAL: 4, PRECISION_MIXED: 8, PRECISION_MIXED_FIXED: 16}
 FETCH_AUTO, FETCH_SCALAR, FETCH_LDS, FETCH_BVH, FETCH_BVH_GLOBAL = 0, 1, 2, 3, 4
 RNG_STOCHASTIC, RNG_DETERMINISTIC = 0, 1
 STAT_SEGMENTS, STAT_SPHERE_TESTS, STAT_KERNEL_NS, STAT_SAMPLES, STAT_WAVE_ITERATIONS, STAT_BVH_NODES, STAT_BVH_TESTS = 0, 1, 2, 3, 4, 5, 6
@@ -80,6 +83,7 @@ class CameraSettings(C.Structure):
 class Options(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_int32), ("precision", C.c_int32), ("sphere_fetch", C.c_int32),
                 ("device", C.c_int32), ("device_count", C.c_int32), ("sample_chunks", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32),
                 ("linear_out", C.POINTER(V3)), ("stats", C.POINTER(C.c_uint64))]
 
 
@@ -249,7 +253,7 @@ def serialize_ppm(image: np.ndarray) -> bytes:
 
 
 def render_ppm(width: int, height: int, camera_render_data: CameraRenderData, spheres: np.ndarray, materials: np.ndarray, *,
-               seed: int = 0, rng_mode: int = RNG_DETERMINISTIC, precision: int = PRECISION_F32, sphere_fetch: int = FETCH_AUTO,
+               seed: int = 0, rng_mode: int = RNG_DETERMINISTIC, precision: int = PRECISION_MIXED, sphere_fetch: int = FETCH_AUTO,
                device: int = -1, device_count: int = 1, sample_chunks: int = 0) -> bytes:
     """render_tiled followed by serialize_ppm (main.odin:840-848) with the quantiser and the text
     formatting on the GPU; the bytes equal serialize_ppm(render_tiled(...))."""
@@ -294,8 +298,8 @@ def rng_u32(seed: int, pixel: int, sample: int, bounce: int, draw: int) -> int:
 
 # ---- the render path -----------------------------------------------------------------
 def render_region(image: np.ndarray, region, camera_render_data: CameraRenderData, spheres: np.ndarray, materials: np.ndarray, *,
-                  seed: int = 0, rng_mode: int = RNG_DETERMINISTIC, precision: int = PRECISION_F32, sphere_fetch: int = FETCH_AUTO,
-                  device: int = -1, device_count: int = 1, sample_chunks: int = 0,
+                  seed: int = 0, rng_mode: int = RNG_DETERMINISTIC, precision: int = PRECISION_MIXED, sphere_fetch: int = FETCH_AUTO,
+                  device: int = -1, device_count: int = 1, sample_chunks: int = 0, flags: int = 0,
                   linear_out: Optional[np.ndarray] = None, want_stats: bool = False):
     """render_region (main.odin:510-591) on the GPU.
 
@@ -311,7 +315,7 @@ def render_region(image: np.ndarray, region, camera_render_data: CameraRenderDat
     o = Options()
     lib().rt_options_default(C.byref(o))
     o.seed, o.rng_mode, o.precision, o.sphere_fetch = seed, rng_mode, precision, sphere_fetch
-    o.device, o.device_count, o.sample_chunks = device, device_count, sample_chunks
+    o.device, o.device_count, o.sample_chunks, o.flags = device, device_count, sample_chunks, flags
     if linear_out is not None:
         if linear_out.dtype != np.float64 or linear_out.shape != image.shape or not linear_out.flags.c_contiguous:
             raise ValueError("linear_out must match image")
@@ -352,7 +356,7 @@ class World:
 
     def render_accumulate(self, cam: CameraRenderData, width: int, height: int, d_accum: int, *, region=None, strip_rows: int = 8,
                           strip_index: int = 0, strip_count: int = 1, sample_begin: int = 0, sample_count: Optional[int] = None,
-                          seed: int = 0, precision: int = PRECISION_F32, sphere_fetch: int = FETCH_AUTO, sample_chunks: int = 0,
+                          seed: int = 0, precision: int = PRECISION_MIXED, sphere_fetch: int = FETCH_AUTO, sample_chunks: int = 0,
                           d_stats: int = 0, stream: int = 0, static_scratch: bool = False) -> None:
         """rt_render_accumulate: d_accum / d_stats / stream are raw device pointers / a hipStream_t.
         static_scratch: rt_render_accumulate_static, the entry point that allocates nothing."""
@@ -364,13 +368,13 @@ class World:
                                           d_accum, d_stats or None, stream or None))
 
     def finalize(self, d_accum: int, width: int, height: int, total_samples: int, d_image: int, *, region=None, strip_rows: int = 8,
-                 strip_index: int = 0, strip_count: int = 1, precision: int = PRECISION_F32, d_linear: int = 0, stream: int = 0) -> None:
+                 strip_index: int = 0, strip_count: int = 1, precision: int = PRECISION_MIXED, d_linear: int = 0, stream: int = 0) -> None:
         region = (0, 0, width, height) if region is None else region
         _check(lib().rt_finalize(self._h, d_accum, precision, width, height, Rect(*[int(v) for v in region]), strip_rows, strip_index,
                                  strip_count, total_samples, d_image, d_linear or None, stream or None))
 
     def finalize_ppm(self, d_accum: int, width: int, height: int, total_samples: int, d_text: int, *, strip_rows: int = 8,
-                     strip_index: int = 0, strip_count: int = 1, precision: int = PRECISION_F32, stream: int = 0) -> None:
+                     strip_index: int = 0, strip_count: int = 1, precision: int = PRECISION_MIXED, stream: int = 0) -> None:
         """the tail of the pixel loop and the body of serialize_ppm (main.odin:577-586, :806-820) on the device:
         12 bytes of text per pixel at d_text + 12 * (u + v*width)"""
         _check(lib().rt_finalize_ppm(self._h, d_accum, precision, width, height, strip_rows, strip_index, strip_count, total_samples,

@@ -58,7 +58,9 @@ void seed_keys(uint64_t seed, uint32_t &k0, uint32_t &k1) {
     k1 = mix32(static_cast<uint32_t>(seed >> 32) ^ k0 ^ 0x85ebca6bu);
 }
 
-bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL || p == RT_PRECISION_MIXED; }
+bool precision_ok(int32_t p) { return p == RT_PRECISION_F32 || p == RT_PRECISION_F64 || p == RT_PRECISION_F32_LITERAL || p == RT_PRECISION_MIXED || p == RT_PRECISION_MIXED_FIXED; }
+static_assert(RT_PRECISION_F32 == rtk::ARITH_F32_FMA && RT_PRECISION_F64 == rtk::ARITH_F64 && RT_PRECISION_F32_LITERAL == rtk::ARITH_F32_LITERAL &&
+              RT_PRECISION_MIXED == rtk::ARITH_MIXED && RT_PRECISION_MIXED_FIXED == rtk::ARITH_MIXED_FIXED, "the ABI's precision values are the kernels' arithmetic modes");
 size_t accum_size(int32_t precision) { return rtk::accum_element_size(precision); }
 
 struct DeviceGuard {
@@ -118,6 +120,7 @@ struct rt_world_s {
     // another stream than the previous such call first waits (on the device) for that call's end.
     void *slabs = nullptr;
     size_t slab_bytes = 0;
+    size_t staging_cap = ~static_cast<size_t>(0); // half the smallest staging request the device has refused so far
     hipEvent_t slabs_done = nullptr;
     hipStream_t slabs_stream = nullptr;
     bool slabs_busy = false;
@@ -196,11 +199,24 @@ int auto_chunks(int32_t n_tiles, int64_t sample_count) {
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(c, 32)));
 }
 
+// Samples per unit of the queue modes (a lane traces that many consecutive samples of one pixel, adds their colours in
+// registers and issues one set of atomics).  RT_MI355X_UNIT_SAMPLES overrides it (a tuning aid).
+int64_t unit_samples() {
+    static const int64_t value = [] {
+        const char *env = std::getenv("RT_MI355X_UNIT_SAMPLES");
+        const long long v = (env != nullptr && env[0] != '\0') ? std::atoll(env) : 0;
+        return static_cast<int64_t>(v >= 1 && v <= 4096 ? v : 4);
+    }();
+    return value;
+}
+
 int auto_queue_chunks(int64_t sample_count) {
-    // work items of about 4 samples per pixel (256 paths): small enough that the items still
+    // work items of a few samples per pixel (some hundred paths): small enough that the items still
     // running when the queue empties are a sliver of the launch, large enough that taking one
-    // (an atomic and a few scalar instructions per wave) costs nothing
-    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + 3) / 4, 4096)));
+    // (an atomic and a few scalar instructions per wave) and flushing a lane's sums (a set of atomics
+    // per unit) cost nothing
+    const int64_t unit = unit_samples();
+    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + unit - 1) / unit, 4096)));
 }
 
 std::atomic<uint64_t> g_call_counter{0};
@@ -223,7 +239,7 @@ void rt_options_default(rt_options *o) {
     if (!o) return;
     std::memset(o, 0, sizeof *o);
     o->rng_mode = RT_RNG_DETERMINISTIC;
-    o->precision = RT_PRECISION_F32;
+    o->precision = RT_PRECISION_MIXED; // the reference computes in f64 (main.odin:19): the default returns that image
     o->sphere_fetch = RT_FETCH_AUTO;
     o->device = -1;
     o->device_count = 1;
@@ -366,15 +382,26 @@ struct ScratchSource {
     bool fixed = false;
 };
 
-// default upper bound of the mixed mode's staging buffer (it holds 24 bytes per pixel and staged sample;
-// a call whose samples do not fit is run as several launches); RT_MI355X_STAGING_MIB overrides it
-size_t staging_budget() {
-    const char *env = std::getenv("RT_MI355X_STAGING_MIB");
+size_t env_mib(const char *name, size_t fallback) {
+    const char *env = std::getenv(name);
     if (env != nullptr && env[0] != '\0') {
         const long long mib = std::atoll(env);
         if (mib > 0) return static_cast<size_t>(mib) << 20;
     }
-    return static_cast<size_t>(12) << 30;
+    return fallback;
+}
+// default upper bound of the ordered mixed mode's staging buffer (it holds 24 bytes per pixel and staged sample;
+// a call whose samples do not fit is run as several launches, each of which costs about a millisecond of ramp-up
+// and tail); RT_MI355X_STAGING_MIB overrides it.  An allocation that fails is retried at half the size.
+size_t staging_budget() { return env_mib("RT_MI355X_STAGING_MIB", static_cast<size_t>(4) << 30); }
+// hipMalloc for the staging buffer.  RT_MI355X_TEST_MALLOC_LIMIT_MIB (a testing aid) makes requests above that size
+// fail as if the device were out of memory, so that the retry path can be exercised on a 288 GB device.
+hipError_t staging_malloc(void **ptr, size_t bytes) {
+    const size_t limit = env_mib("RT_MI355X_TEST_MALLOC_LIMIT_MIB", ~static_cast<size_t>(0));
+    if (bytes > limit) return hipErrorOutOfMemory;
+    const hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) { *ptr = nullptr; (void)hipGetLastError(); }
+    return e;
 }
 
 int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64_t width, int64_t height, rt_rect region,
@@ -386,7 +413,8 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     if (sphere_fetch < RT_FETCH_AUTO || sphere_fetch > RT_FETCH_BVH_GLOBAL) return fail(RT_ERR_INVALID_ARGUMENT, "unknown sphere_fetch %d", sphere_fetch);
     const bool bvh_global_only = sphere_fetch == RT_FETCH_BVH_GLOBAL;
     if (bvh_global_only) sphere_fetch = RT_FETCH_BVH;
-    if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32 && precision != RT_PRECISION_MIXED) return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32 and RT_PRECISION_MIXED only");
+    if (sphere_fetch == RT_FETCH_BVH && precision != RT_PRECISION_F32 && precision != RT_PRECISION_MIXED && precision != RT_PRECISION_MIXED_FIXED)
+        return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_BVH is available with RT_PRECISION_F32, RT_PRECISION_MIXED and RT_PRECISION_MIXED_FIXED only");
     if (sample_begin < 0 || sample_count < 0 || sample_begin + sample_count > (int64_t(1) << 32) - 2) return fail(RT_ERR_INVALID_ARGUMENT, "samples [%lld, +%lld) outside [0, 2^32-2)", (long long)sample_begin, (long long)sample_count);
     if (cam->max_ray_bounces < 0 || cam->max_ray_bounces > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "max_ray_bounces %lld outside [0, 2^20]", (long long)cam->max_ray_bounces);
     if (sample_chunks < 0) return fail(RT_ERR_INVALID_ARGUMENT, "sample_chunks %d < 0", sample_chunks);
@@ -399,15 +427,18 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     // kernel with one sample chunk, which is the same arithmetic and the same summation order.
     bool mixed = precision == RT_PRECISION_MIXED;
     if (mixed && !world->filter_ok) { mixed = false; precision = RT_PRECISION_F64; sample_chunks = 1; if (sphere_fetch == RT_FETCH_BVH) sphere_fetch = RT_FETCH_SCALAR; }
-    if (mixed && sphere_fetch == RT_FETCH_LDS) return fail(RT_ERR_UNSUPPORTED, "RT_PRECISION_MIXED reads its filter records through the scalar cache only");
+    // fixed-point sums: the same kernel, and a world outside the filter's range keeps every sphere of every ray (list scan)
+    const bool mixed_fixed = precision == RT_PRECISION_MIXED_FIXED;
+    if (mixed_fixed && !world->filter_ok && sphere_fetch == RT_FETCH_BVH) sphere_fetch = RT_FETCH_SCALAR;
+    if ((mixed || mixed_fixed) && sphere_fetch == RT_FETCH_LDS) return fail(RT_ERR_UNSUPPORTED, "RT_PRECISION_MIXED reads its filter records through the scalar cache only");
 
-    const bool f64 = precision == RT_PRECISION_F64 || mixed;
+    const bool f64 = precision == RT_PRECISION_F64 || mixed || mixed_fixed;
     int fetch = sphere_fetch == RT_FETCH_AUTO ? RT_FETCH_SCALAR : sphere_fetch;
     if (fetch == RT_FETCH_LDS && world->n_spheres > (f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32))
         return fail(RT_ERR_UNSUPPORTED, "RT_FETCH_LDS holds at most %d spheres at this precision, the world has %d",
                     f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32, world->n_spheres);
 
-    const bool queue_mode = precision == RT_PRECISION_F32 || mixed;
+    const bool queue_mode = precision == RT_PRECISION_F32 || mixed || mixed_fixed;
     int chunks = sample_chunks > 0 && !mixed ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count) : auto_chunks(wk.map.n_tiles, sample_count));
     chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, sample_count))));
     int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
@@ -426,10 +457,10 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     if (mixed) {
         const size_t per_sample = static_cast<size_t>(slab_stride) * sizeof(double);
         const size_t all = per_sample * static_cast<size_t>(std::max<int64_t>(sample_count, 1));
-        const size_t cap = src.fixed ? src.work_bytes : std::max(per_sample, std::min(all, staging_budget()));
+        const size_t cap = src.fixed ? src.work_bytes : std::max(per_sample, std::min(all, std::min(staging_budget(), world->staging_cap)));
         if (cap < per_sample) return fail(RT_ERR_UNSUPPORTED, "one staged sample of this call needs %zu bytes of scratch, %zu are available", per_sample, cap);
         window = std::max<int64_t>(1, std::min<int64_t>(sample_count, static_cast<int64_t>(cap / per_sample)));
-        if (window < sample_count && window >= 4) window = window / 4 * 4; // whole work items
+        if (window < sample_count && window >= unit_samples()) window = window / unit_samples() * unit_samples(); // whole work items
         work_need = per_sample * static_cast<size_t>(window);
     } else if (chunks > 1 && !queue_mode) {
         work_need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * accum_size(precision);
@@ -442,7 +473,16 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         } else {
             if (work_need > world->slab_bytes) {
                 if (world->slabs) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(world->slabs)); world->slabs = nullptr; world->slab_bytes = 0; world->slabs_busy = false; }
-                HIP_TRY(hipMalloc(&world->slabs, work_need));
+                hipError_t me = staging_malloc(&world->slabs, work_need);
+                // the staged samples are a window that can be any size down to one sample: halve it until it fits
+                while (me == hipErrorOutOfMemory && mixed && window > 1) {
+                    world->staging_cap = work_need / 2; // later calls start from what fitted
+                    window = std::max<int64_t>(1, window / 2);
+                    if (window >= unit_samples()) window = window / unit_samples() * unit_samples();
+                    work_need = static_cast<size_t>(slab_stride) * sizeof(double) * static_cast<size_t>(window);
+                    me = staging_malloc(&world->slabs, work_need);
+                }
+                if (me != hipSuccess) return fail(RT_ERR_DEVICE, "allocating %zu bytes of scratch failed: %s", work_need, hipGetErrorString(me));
                 world->slab_bytes = work_need;
             }
             work = world->slabs;
@@ -521,6 +561,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
 
     rtk::ReduceParams r{};
     r.accum = d_accum; r.slabs = work; r.slab_stride = slab_stride; r.chunks = chunks;
+    r.words_per_pixel = mixed_fixed ? 6 : 3;
     r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
     HIP_TRY(hipEventRecord(slot.ev_begin, st));
     slot.used = true; // from here on something of this call may be in flight
@@ -530,10 +571,11 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         // colours to the accumulators in sample order
         for (int64_t w0 = 0; w0 < std::max<int64_t>(sample_count, 1); w0 += window) {
             const int64_t wc = std::min<int64_t>(window, sample_count - w0);
-            const int wchunks = static_cast<int>(std::max<int64_t>(1, (wc + 3) / 4));
+            const int64_t unit = unit_samples();
+            const int wchunks = static_cast<int>(std::max<int64_t>(1, (wc + unit - 1) / unit));
             p.sample_begin = static_cast<uint32_t>(sample_begin + w0);
             p.sample_count = static_cast<uint32_t>(wc);
-            p.chunk_samples = 4u;
+            p.chunk_samples = static_cast<uint32_t>(unit);
             p.n_items = static_cast<uint32_t>(static_cast<int64_t>(wk.map.n_tiles) * wchunks);
             r.chunks = static_cast<int32_t>(wc);
             HIP_TRY(rtk::launch_clear_queue(queue, st));
@@ -698,6 +740,7 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     if ((image_data == nullptr && ppm_body == nullptr) || cam == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer or cam is NULL");
     if (!precision_ok(o.precision)) return fail(RT_ERR_INVALID_ARGUMENT, "unknown precision %d", o.precision);
     if (o.rng_mode != RT_RNG_STOCHASTIC && o.rng_mode != RT_RNG_DETERMINISTIC) return fail(RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %d", o.rng_mode);
+    if ((o.flags & ~RT_FLAG_PRINT_PROGRESS) != 0) return fail(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags 0x%x", static_cast<unsigned>(o.flags));
     // the reference divides by samples_per_pixel (main.odin:512); zero or negative counts have no meaningful image
     if (cam->samples_per_pixel < 1) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel %lld < 1", (long long)cam->samples_per_pixel);
     int32_t rc = validate_scene(spheres, n_spheres, materials, n_materials);
@@ -922,6 +965,8 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
     }
     if (result == RT_OK && o.stats)
         o.stats[RT_STAT_SPHERE_TESTS] = (o.sphere_fetch == RT_FETCH_BVH || o.sphere_fetch == RT_FETCH_BVH_GLOBAL) ? o.stats[RT_STAT_BVH_TESTS] : o.stats[RT_STAT_SEGMENTS] * static_cast<uint64_t>(n_spheres);
+    // $print_progress of render_region: the reference's closing line (main.odin:590)
+    if (result == RT_OK && (o.flags & RT_FLAG_PRINT_PROGRESS) != 0) std::fputs("\rDone.                   \n", stderr);
     const std::string keep = g_error;
     cleanup();
     (void)hipSetDevice(prev_device);

@@ -21,8 +21,10 @@ constexpr int LDS_MAX_SPHERES_F64 = 2040; // just under 64 KiB of double4 record
 // ARITH_F32_LITERAL: f32, reference operation order, accumulators are float
 // ARITH_MIXED      : f64, reference operation order, behind the packed-f32 scan used as a conservative
 //                    filter; work queue; every sample colour is staged and summed in sample order
-enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2, ARITH_MIXED = 3 };
-inline size_t accum_element_size(int arith) { return arith == ARITH_F32_LITERAL ? 4 : 8; }
+// ARITH_MIXED_FIXED: the paths of ARITH_MIXED; every sample colour is added to its pixel's accumulators as a Q32.64
+//                    fixed-point number, two uint64 words per channel {units of 2^-32, units of 2^-64} (atomic adds)
+enum Arith { ARITH_F32_FMA = 0, ARITH_F64 = 1, ARITH_F32_LITERAL = 2, ARITH_MIXED = 3, ARITH_MIXED_FIXED = 4 };
+inline size_t accum_element_size(int arith) { return arith == ARITH_F32_LITERAL ? 4 : (arith == ARITH_MIXED_FIXED ? 16 : 8); }
 enum Fetch { FETCH_SCALAR = 1, FETCH_LDS = 2, FETCH_BVH = 3 };
 
 // camera_render_data (main.odin:440-448) as 19 numbers in the kernel's arithmetic type:
@@ -89,6 +91,7 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
 
 struct ReduceParams {
     void *accum; const void *slabs; int64_t slab_stride; int32_t chunks;
+    int32_t words_per_pixel; // launch_clear: 64-bit words of accumulator per pixel (3: Q32.32, 6: Q32.64)
     int32_t width; int32_t min_x, min_y, max_x, max_y; TileMap map;
 };
 // accum[p] = accum[p] + slab_0[p] + slab_1[p] + ... (chunk order) for the pixels the TileMap owns

@@ -5,11 +5,14 @@
 //   segment: the closest-hit scan over all spheres, then shading.  A lane whose path ended
 //   starts another sample in the same iteration, so lanes never wait for the longest path.
 //   Throughput mode (QUEUE): work items are (tile, sample chunk) pairs behind one global
-//   counter.  A wave takes an item, deals its (pixel, sample) pairs to whichever lanes are
-//   free, and takes the next item when the pairs run out, while other lanes are still finishing
+//   counter.  A wave takes an item, deals its units -- (pixel, sample) pairs -- to whichever lanes
+//   are free, and takes the next item when the units run out, while other lanes are still finishing
 //   paths of the previous one.  A finished sample is added to its pixel's Q32.32 accumulator in
 //   HBM with integer atomics, so the sums are exact and independent of which lane, wave or GPU
 //   traced what.  Lanes idle only when the whole queue is empty.
+//   (Fixed-point mixed mode: a unit is one pixel's samples of the chunk; the lane adds their colours
+//   in registers and issues its atomics once per unit -- six 64-bit atomics per sample would exceed
+//   the rate at which the memory side executes them, three do not.)
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
 //   Mixed mode: f64 paths in the reference's operation order behind the f32 filter scan, whose
@@ -187,7 +190,36 @@ __device__ __forceinline__ unsigned long long to_q32_32(float x) {
     const uint32_t lo = static_cast<uint32_t>(fr * 4294967296.0f);
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
-__device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; } // never used: QUEUE is f32 only
+__device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; } // never used: the f64 queue modes stage or use Q32.64
+// Q32.64 fixed point of a non-negative f64 as two words: a = floor(x * 2^32) (units of 2^-32), b = the next 32 bits
+// (units of 2^-64); x is truncated below 2^-64, NaN and negatives give 0, x >= 2^32 saturates.  Every step is exact:
+// the differences are of numbers on a common grid and below one unit of the part already taken.  Word sums of up to
+// 2^32 samples cannot overflow (a < 2^64 needs sum x < 2^32; b < 2^32 per sample).
+__device__ __forceinline__ void to_q32_64(double x, unsigned long long &a, unsigned long long &b) {
+    a = 0ull; b = 0ull;
+    if (!(x > 0.0)) return;
+    if (x >= 4294967296.0) { a = 0xFFFFFFFFFFFFFFFFull; b = 0xFFFFFFFFull; return; }
+    const uint32_t hi = static_cast<uint32_t>(x);                 // truncates
+    const double t1 = (x - static_cast<double>(hi)) * 4294967296.0; // in [0, 2^32)
+    const uint32_t mid = static_cast<uint32_t>(t1);
+    const double t2 = (t1 - static_cast<double>(mid)) * 4294967296.0;
+    a = (static_cast<unsigned long long>(hi) << 32) | mid;
+    b = static_cast<unsigned long long>(static_cast<uint32_t>(t2));
+}
+// The sum held by the two words, a * 2^-32 + b * 2^-64, rounded to f64 once (to nearest, ties to even): the 128-bit
+// integer T = a * 2^32 + b is normalised, its top 64 bits taken with everything below them OR-ed into the lowest (far
+// below the 53 bits that survive, so it only breaks ties), converted (u64 -> f64 is one correctly rounded
+// operation: two exact halves and one addition) and scaled by a power of two.
+__device__ __forceinline__ double q32_64_to_f64(unsigned long long a, unsigned long long b) {
+    unsigned long long lo = (a << 32) + b;
+    unsigned long long hi = (a >> 32) + (lo < b ? 1ull : 0ull);
+    if (hi == 0ull) return static_cast<double>(lo) * 5.421010862427522e-20; // 2^-64
+    const int shift = __builtin_clzll(hi); // hi < 2^34: shift >= 30
+    unsigned long long top = (hi << shift) | (shift == 0 ? 0ull : (lo >> (64 - shift)));
+    const unsigned long long rest = shift == 0 ? lo : (lo << shift);
+    if (rest != 0ull) top |= 1ull;
+    return __builtin_ldexp(static_cast<double>(top), -shift); // top * 2^(64 - shift) * 2^-64
+}
 
 typedef float F2 __attribute__((ext_vector_type(2)));
 struct Pair { F2 cx, cy, cz, k; }; // two spheres' scan records, component-wise
@@ -205,7 +237,9 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 // Through the hierarchy the mixed kernel waits on LDS or memory rather than on the vector pipe and more waves pay
 // (same box, 300 spp: LDS form 46.3 ms at four, 47.0 at five -- 512-thread workgroups, so five is four --, 44.2 at
 // six, 65 at eight; global form 51.0 at four and six, 46.5 at five).
-#define RT_MIXED_WAVES (BVH == 2 ? 6 : (BVH == 1 ? 5 : 4))
+// The fixed-point variants carry nine more registers (a unit's sums): four waves throughout (same box, 300 spp, LDS / global
+// form: 54.3 / 60.9 ms at six / five waves, 51.4 / 58.6 at four).
+#define RT_MIXED_WAVES (FIXED ? 4 : (BVH == 2 ? 6 : (BVH == 1 ? 5 : 4)))
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(MIXED ? RT_MIXED_WAVES : 1, MIXED ? RT_MIXED_WAVES : 8)))
 #else
 #define RT_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
@@ -219,10 +253,13 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 //        rounding error the f32 evaluation can have made.  Samples are dealt to free lanes (QUEUE)
 //        and every finished sample colour is stored, so that a second kernel can add them in
 //        sample order (main.odin:575).
-template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0, bool MIXED = false>
+// FIXED (with MIXED): a finished sample's colour is added to its pixel's Q32.64 accumulators with integer atomics
+//        (exact, order-independent) instead of being staged for the ordered sum.
+template <typename Real, bool FMA, int FETCH, bool QUEUE, int BVH = 0, bool MIXED = false, bool FIXED = false>
 __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) RT_WAVES_PER_EU_ATTR void render_kernel(const RenderParams P) {
     static_assert(BVH == 0 || ((FMA || MIXED) && QUEUE && FETCH == FETCH_SCALAR), "the hierarchy is traversed in f32, by the throughput and the mixed mode");
     static_assert(!MIXED || (std::is_same<Real, double>::value && !FMA && QUEUE && FETCH == FETCH_SCALAR), "the mixed mode is f64 literal arithmetic behind the scalar-fetch f32 filter");
+    static_assert(!FIXED || MIXED, "fixed-point sums of f64 colours belong to the mixed mode");
     constexpr bool FILTER = FMA || MIXED; // the scan is the packed-f32 candidate filter
     // Candidates of the filter go to a queue per wave in LDS and are evaluated 64 at a time by whichever lanes there
     // are, instead of each lane evaluating its own as they come (which ran the evaluation code about four times per
@@ -293,12 +330,24 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // literal modes: one tile and one sample chunk per wave
     uint32_t s_end = 0;
     bool inside = false;
-    // queue mode, all wave-uniform: the current item and its (pixel, sample) pairs
-    uint32_t pair_next = 0, pair_total = 0, npx = 0, item_s_begin = 0;
+    // A unit of work in queue mode: one (pixel, sample) pair; with UNITS one pixel's samples of the item's chunk, whose
+    // colours the lane adds up in registers.  Measured on the headline frame: per-pixel units cost the throughput and
+    // the ordered mixed mode 2-5 % (a pixel's paths are alike, so the lanes that drew the long ones fall behind the
+    // others and the wave's iterations are worse filled; wave-level dealing runs as often either way), and save the
+    // fixed-point mixed mode 7 % (1.5 atomics per sample instead of 6, which is more than the memory side executes).
+    constexpr bool UNITS = MIXED && FIXED;
+    // queue mode, all wave-uniform: the current item and its units
+    uint32_t unit_next = 0, unit_total = 0, npx = 0, item_s_begin = 0, item_s_end = 0;
     int x0 = 0, y0 = 0, tw = TILE, item_tile = 0;
     bool queue_open = true;
-    // mixed mode: where this lane's sample colour is stored, ((sample of the launch) * owned pixels + tile * 64 + pixel of the tile) * 3
-    int64_t stage_at = 0;
+    // queue mode, per lane: the lane has no unit (and asks for one); one past the last sample of its unit
+    bool need_unit = QUEUE;
+    uint32_t unit_end = 0;
+    // ordered mixed mode: where this lane's sample colours are stored, (tile * 64 + pixel of the tile) * 3 within a sample's slab
+    int64_t stage_px = 0;
+    // fixed-point mixed mode: the sum of the unit's sample colours in Q32.64 as {units of 2^-32, units of 2^-64}
+    unsigned long long sum_q[3] = {0ull, 0ull, 0ull};
+    uint32_t sum_lo[3] = {0u, 0u, 0u};
 
     if constexpr (!QUEUE) {
         const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -317,7 +366,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     V3<Real> color = {Real(1), Real(1), Real(1)};                                // sample_color
     V3<Real> acc = {Real(0), Real(0), Real(0)};                                  // pixel_color (literal modes)
     int bounce = 0;
-    bool fresh = true;
+    bool fresh = !QUEUE; // the lane starts a camera ray in this iteration
     // throughput arithmetic: the sphere the current segment starts on (-1 for a camera ray) and its centre
     int start_sphere = -1;
     V3<Real> start_center = {Real(0), Real(0), Real(0)};
@@ -355,13 +404,13 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
 #endif
     for (;;) {
         if constexpr (QUEUE) {
-            // Deal (pixel, sample) pairs to the lanes that need one, in lane order, taking new
-            // items from the global queue as the current one runs out.  `pending` and all queue
-            // state are wave-uniform, so this loop does not diverge.
-            unsigned long long pending = __builtin_amdgcn_ballot_w64(fresh);
+            // Deal units to the lanes that need one, in lane order, taking new items from the global
+            // queue as the current one runs out.  `pending` and all queue state are wave-uniform, so
+            // this loop does not diverge.
+            unsigned long long pending = __builtin_amdgcn_ballot_w64(need_unit);
             bool got = false;
             while (pending != 0ull) {
-                if (pair_next >= pair_total) {
+                if (unit_next >= unit_total) {
                     if (!queue_open) break;
                     uint32_t item = 0u;
                     if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) item = atomicAdd(P.queue, 1u); // one lane per wave
@@ -373,33 +422,43 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     x0 = P.min_x + (tile % P.map.tiles_x) * TILE;
                     y0 = P.min_y + tile_row_of(P.map, tile / P.map.tiles_x) * TILE;
                     tw = min(TILE, P.max_x - x0);
-                    npx = static_cast<uint32_t>(tw * min(TILE, P.max_y - y0)); // pixels of the tile inside the region
                     item_s_begin = min(P.sample_count, chunk * P.chunk_samples);
-                    pair_total = npx * (min(P.sample_count, item_s_begin + P.chunk_samples) - item_s_begin);
-                    pair_next = 0u;
+                    item_s_end = min(P.sample_count, item_s_begin + P.chunk_samples);
+                    npx = static_cast<uint32_t>(tw * min(TILE, P.max_y - y0)); // pixels of the tile inside the region
+                    unit_total = UNITS ? (item_s_end > item_s_begin ? npx : 0u) : npx * (item_s_end - item_s_begin);
+                    unit_next = 0u;
                     continue;
                 }
-                const uint32_t avail = pair_total - pair_next;
-                const bool take = fresh && !got && rank_in(pending) < avail;
+                const uint32_t avail = unit_total - unit_next;
+                const bool take = need_unit && !got && rank_in(pending) < avail;
                 if (take) {
-                    const uint32_t pair = pair_next + rank_in(pending);
-                    uint32_t q, si; // pixel within the tile, sample within the item
-                    if (npx == 64u) { q = pair & 63u; si = pair >> 6; } else { q = pair % npx; si = pair / npx; }
-                    s = item_s_begin + si;
+                    const uint32_t index = unit_next + rank_in(pending);
+                    uint32_t q; // pixel within the tile
+                    if constexpr (UNITS) { q = index; s = item_s_begin; unit_end = item_s_end; }
+                    else {
+                        uint32_t si; // sample within the item
+                        if (npx == 64u) { q = index & 63u; si = index >> 6; } else { q = index % npx; si = index / npx; }
+                        s = item_s_begin + si;
+                        unit_end = s + 1u;
+                    }
                     if (tw == TILE) { u = x0 + static_cast<int>(q & 7u); v = y0 + static_cast<int>(q >> 3); }
                     else { u = x0 + static_cast<int>(q % static_cast<uint32_t>(tw)); v = y0 + static_cast<int>(q / static_cast<uint32_t>(tw)); }
                     pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
                     kp = mix32(P.k0 ^ pixel);
                     wp = mix32(P.k1 + pixel);
-                    if constexpr (MIXED)
-                        stage_at = static_cast<int64_t>(s) * P.slab_stride + (static_cast<int64_t>(item_tile) * 64 + (v - y0) * TILE + (u - x0)) * 3;
+                    if constexpr (MIXED && !FIXED)
+                        stage_px = (static_cast<int64_t>(item_tile) * 64 + (v - y0) * TILE + (u - x0)) * 3;
                     got = true;
                 }
                 const unsigned long long taken = __builtin_amdgcn_ballot_w64(take);
-                pair_next += static_cast<uint32_t>(__builtin_popcountll(taken));
+                unit_next += static_cast<uint32_t>(__builtin_popcountll(taken));
                 pending &= ~taken;
             }
-            if (fresh && !got) break; // the queue is empty: this lane is done
+            if (need_unit) {
+                if (!got) break; // the queue is empty: this lane is done
+                need_unit = false;
+                fresh = true;
+            }
         } else {
             if (fresh && !(inside && s < s_end)) break;
         }
@@ -1100,9 +1159,20 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         }
         if (ended) {
             // pixel_color += sample_color (main.odin:575)
-            if constexpr (MIXED) {
+            if constexpr (MIXED && FIXED) {
+                // Q32.64 in registers: exact integer sums, whatever the order in which lanes, waves or GPUs finish samples
+                const Real ch[3] = {color.x, color.y, color.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned long long wa, wb;
+                    to_q32_64(ch[c], wa, wb);
+                    const uint32_t lo = sum_lo[c] + static_cast<uint32_t>(wb);
+                    sum_q[c] += wa + (lo < sum_lo[c] ? 1ull : 0ull); // the carry of the low word
+                    sum_lo[c] = lo;
+                }
+            } else if constexpr (MIXED) {
                 // the sample's colour goes to its own slot; order_sum_kernel adds the slots in sample order
-                double *dst = static_cast<double *>(P.slabs) + stage_at;
+                double *dst = static_cast<double *>(P.slabs) + (static_cast<int64_t>(s) * P.slab_stride + stage_px);
                 dst[0] = color.x; dst[1] = color.y; dst[2] = color.z;
             } else if constexpr (QUEUE) {
                 unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * 3;
@@ -1111,9 +1181,26 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 atomicAdd(dst + 2, to_q32_32(color.z));
             } else {
                 acc = acc + color;
-                ++s;
             }
-            fresh = true;
+            ++s;
+            if constexpr (QUEUE) {
+                if (s >= unit_end) {
+                    // the unit is done: its sums go to the pixel's accumulators, and the lane asks for another unit
+                    if constexpr (MIXED && FIXED) {
+                        unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * 6;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            atomicAdd(dst + 2 * c, sum_q[c]); atomicAdd(dst + 2 * c + 1, static_cast<unsigned long long>(sum_lo[c]));
+                            sum_q[c] = 0ull; sum_lo[c] = 0u;
+                        }
+                    }
+                    need_unit = true;
+                } else {
+                    fresh = true; // the next sample of the same pixel
+                }
+            } else {
+                fresh = true;
+            }
         }
         RT_PHASE(ph_end);
     }
@@ -1198,8 +1285,8 @@ __global__ void clear_kernel(const ReduceParams P, uint32_t *queue) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *queue = 0u;
     int64_t idx;
     if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
-    unsigned long long *a = static_cast<unsigned long long *>(P.accum) + idx * 3;
-    a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
+    unsigned long long *a = static_cast<unsigned long long *>(P.accum) + idx * P.words_per_pixel;
+    for (int k = 0; k < P.words_per_pixel; ++k) a[k] = 0ull;
 }
 
 __global__ void clear_queue_kernel(uint32_t *queue) { *queue = 0u; }
@@ -1266,6 +1353,19 @@ __global__ void finalize_q_kernel(const FinalizeParams P) {
     }
 }
 
+// The same tail for Q32.64 sums: the sum rounded to f64 once, * 1/spp, sqrt.
+__global__ void finalize_q2_kernel(const FinalizeParams P) {
+    int64_t idx;
+    if (!owned_pixel(P.map, P.min_x, P.min_y, P.max_x, P.max_y, P.width, idx)) return;
+    const unsigned long long *in = static_cast<const unsigned long long *>(P.accum) + idx * 6;
+    const double contribution = 1.0 / static_cast<double>(P.total_samples);
+    for (int c = 0; c < 3; ++c) {
+        const double mean = q32_64_to_f64(in[2 * c], in[2 * c + 1]) * contribution;
+        if (P.linear != nullptr) P.linear[idx * 3 + c] = mean;
+        P.image[idx * 3 + c] = sqrt_rn(mean);
+    }
+}
+
 // serialize_ppm's body on the device (main.odin:806-820): each channel is
 // u8(256 * min(x, 0.999)) printed right-aligned in three columns and followed by ' ' (after blue:
 // '\n'), i.e. one little-endian 32-bit word per channel.  The gamma value x is formed exactly as
@@ -1287,6 +1387,10 @@ template <int ARITH> __global__ void finalize_ppm_kernel(const PpmParams P) {
         const unsigned long long *in = static_cast<const unsigned long long *>(P.accum) + idx * 3;
         const double contribution = 1.0 / static_cast<double>(P.total_samples);
         for (int c = 0; c < 3; ++c) g[c] = sqrt_rn((q32_32_to_f64(in[c]) * (1.0 / 4294967296.0)) * contribution);
+    } else if constexpr (ARITH == ARITH_MIXED_FIXED) {
+        const unsigned long long *in = static_cast<const unsigned long long *>(P.accum) + idx * 6;
+        const double contribution = 1.0 / static_cast<double>(P.total_samples);
+        for (int c = 0; c < 3; ++c) g[c] = sqrt_rn(q32_64_to_f64(in[2 * c], in[2 * c + 1]) * contribution);
     } else {
         using Real = typename std::conditional<ARITH == ARITH_F64, double, float>::type;
         const Real *in = static_cast<const Real *>(P.accum) + idx * 3;
@@ -1365,6 +1469,19 @@ hipError_t launch_render(const RenderParams &p, int arith, int fetch, int chunks
         else launch_k(render_kernel<double, false, FETCH_SCALAR, true, 0, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
         break;
     }
+    case ARITH_MIXED_FIXED: {
+        const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(resident_blocks, (static_cast<int64_t>(p.n_items) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)));
+        if (fetch == FETCH_BVH && p.bvh_lds_boxes != nullptr) {
+            // this instantiation is built for four waves per SIMD: two workgroups of 512 per CU
+            const size_t lds_bytes = static_cast<size_t>(p.bvh_n_nodes) * 48;
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(4 * 256 / BVH_LDS_BLOCK_THREADS, (160 * 1024) / std::max<size_t>(lds_bytes, 1))));
+            const int fit = std::max(1, resident_blocks / 8 * per_cu);
+            const int wanted = static_cast<int>((static_cast<int64_t>(p.n_items) + BVH_LDS_BLOCK_THREADS / 64 - 1) / (BVH_LDS_BLOCK_THREADS / 64));
+            hipLaunchKernelGGL((render_kernel<double, false, FETCH_SCALAR, true, 2, true, true>), dim3(std::max(1, std::min(wanted, fit))), dim3(BVH_LDS_BLOCK_THREADS, 1, 1), lds_bytes, stream, p);
+        } else if (fetch == FETCH_BVH) launch_k(render_kernel<double, false, FETCH_SCALAR, true, 1, true, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        else launch_k(render_kernel<double, false, FETCH_SCALAR, true, 0, true, true>, dim3(grid), FETCH_SCALAR, p.n_spheres, sizeof(float4), stream, p);
+        break;
+    }
     case ARITH_F32_LITERAL:
         if (lds) launch_k(render_kernel<float, false, FETCH_LDS, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
         else launch_k(render_kernel<float, false, FETCH_SCALAR, false>, dim3(blocks, chunks), fetch, p.n_spheres, sizeof(float4), stream, p);
@@ -1394,7 +1511,7 @@ hipError_t launch_order_sum(const ReduceParams &p, bool first, hipStream_t strea
 }
 
 hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
-    if (p.map.n_tiles <= 0 || p.chunks <= 1 || arith == ARITH_F32_FMA || arith == ARITH_MIXED) return hipSuccess;
+    if (p.map.n_tiles <= 0 || p.chunks <= 1 || arith == ARITH_F32_FMA || arith == ARITH_MIXED || arith == ARITH_MIXED_FIXED) return hipSuccess;
     if (arith == ARITH_F64) hipLaunchKernelGGL(reduce_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(reduce_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
@@ -1403,6 +1520,7 @@ hipError_t launch_reduce(const ReduceParams &p, int arith, hipStream_t stream) {
 hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t stream) {
     if (p.map.n_tiles <= 0) return hipSuccess;
     if (arith == ARITH_F64 || arith == ARITH_MIXED) hipLaunchKernelGGL(finalize_kernel<double>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else if (arith == ARITH_MIXED_FIXED) hipLaunchKernelGGL(finalize_q2_kernel, pixel_grid(p.map), dim3(256), 0, stream, p);
     else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_q_kernel, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(finalize_kernel<float>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();
@@ -1411,6 +1529,7 @@ hipError_t launch_finalize(const FinalizeParams &p, int arith, hipStream_t strea
 hipError_t launch_finalize_ppm(const PpmParams &p, int arith, hipStream_t stream) {
     if (p.map.n_tiles <= 0) return hipSuccess;
     if (arith == ARITH_F64 || arith == ARITH_MIXED) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F64>, pixel_grid(p.map), dim3(256), 0, stream, p);
+    else if (arith == ARITH_MIXED_FIXED) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_MIXED_FIXED>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else if (arith == ARITH_F32_FMA) hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_FMA>, pixel_grid(p.map), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(finalize_ppm_kernel<ARITH_F32_LITERAL>, pixel_grid(p.map), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -8,8 +8,9 @@ tile pool is a partition of pixels into disjoint rects (main.odin:657-681):
             each rank finalises its strips, packs them into a strip-major buffer of its own rows
             and rank 0 gathers exactly those rows (height/N rows per rank, no reduction).
   samples : rank r traces its share of the global sample indices of every pixel; the exact
-            accumulators (Q32.32 integers) are summed with one all-reduce, so the result is
-            bitwise the single-GPU image of all the samples, and rank 0 finalises.
+            accumulators (fixed-point integers: Q32.32 of the f32 mode, Q32.64 of the fixed-point mixed
+            mode) are summed with one all-reduce, so the result is bitwise the single-GPU image of
+            all the samples, and rank 0 finalises.
 
 Scaling: by default the frame is FIXED (strong scaling: N ranks share one frame of `spp`
 samples per pixel); `weak=True` with the sample partition gives every rank `spp` samples of
@@ -104,22 +105,59 @@ class RowGather:
         return gathered
 
 
-def render_step(plan: Plan, dist, accum, image, gathered, trace: Callable, finish: Callable, gather: RowGather | None = None):
+class StepTimers:
+    """Device-side times of the two parts of a step on this rank's stream: the render part (trace, and for the row
+    partition the finalise) and the collective part (all-reduce + finalise, or gather + scatter of rows).  Events are
+    recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def add(self, begin, middle, end):
+        self.marks.append((begin, middle, end))
+
+    def means_ms(self):
+        """(render part, collective part) in ms, means over the recorded steps; synchronises"""
+        import torch
+        torch.cuda.synchronize()
+        if not self.marks:
+            return 0.0, 0.0
+        render = sum(b.elapsed_time(m) for b, m, _ in self.marks) / len(self.marks)
+        coll = sum(m.elapsed_time(e) for _, m, e in self.marks) / len(self.marks)
+        return render, coll
+
+
+def render_step(plan: Plan, dist, accum, image, gathered, trace: Callable, finish: Callable, gather: RowGather | None = None,
+                timers: StepTimers | None = None):
     """One frame.  accum: the rank's accumulators, image: its finalised image (only its strips are
     written), gathered: rank 0's output buffer.  Returns the buffer holding the frame on rank 0."""
     rows, index, count = plan.strips
     begin, n = plan.sample_range
+    t0 = timers.mark() if timers else None
     if plan.partition == "samples":
         trace(accum, strip_rows=rows, strip_index=0, strip_count=1, sample_begin=begin, sample_count=n)
+        t1 = timers.mark() if timers else None
         if plan.world_size > 1:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)
         if plan.rank == 0:
             finish(accum, image, total_samples=plan.total_spp, strip_rows=rows, strip_index=0, strip_count=1)
+        if timers:
+            timers.add(t0, t1, timers.mark())
         return image
     trace(accum, strip_rows=rows, strip_index=index, strip_count=count, sample_begin=begin, sample_count=n)
     finish(accum, image, total_samples=plan.spp, strip_rows=rows, strip_index=index, strip_count=count)
     if plan.world_size == 1:
         return image
+    t1 = timers.mark() if timers else None
     if gather is None:
         gather = RowGather(plan, image)
-    return gather.run(dist, image, gathered)
+    out = gather.run(dist, image, gathered)
+    if timers:
+        timers.add(t0, t1, timers.mark())
+    return out

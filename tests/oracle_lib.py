@@ -21,6 +21,8 @@ class Oracle:
         L.oracle_render_region.argtypes = [i32, vp, vp, vp, i64, i64, rt.Rect, C.POINTER(rt.CameraRenderData), vp, i64, vp, i64,
                                            u64, i64, i64, i64, vp, i32]
         L.oracle_render_region.restype = i32
+        L.oracle_render_fixed_words.argtypes = [vp, i64, i64, rt.Rect, C.POINTER(rt.CameraRenderData), vp, i64, vp, i64, u64, i64, i64, i32]
+        L.oracle_render_fixed_words.restype = i32
         L.oracle_ray_sphere_intersection.argtypes = [i32, vp, vp, vp, dbl, dbl, dbl]
         L.oracle_ray_sphere_intersection.restype = dbl
         L.oracle_material_scatter.argtypes = [i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, u32, vp]
@@ -53,6 +55,17 @@ class Oracle:
                                          stats.ctypes.data, threads)
         assert rc == 0
         return dict(image=image, linear=linear, accum=accum, stats=stats)
+
+    def render_fixed_words(self, width, height, region, cam, spheres, materials, *, seed=0, sample_begin=0, sample_count=None, threads=1):
+        """RT_PRECISION_MIXED_FIXED: the accumulator words, (h, w, 3, 2) uint64 {units of 2^-32, units of 2^-64}"""
+        spheres = np.ascontiguousarray(spheres, dtype=rt.SPHERE_DTYPE)
+        materials = np.ascontiguousarray(materials, dtype=rt.MATERIAL_DTYPE)
+        words = np.zeros((height, width, 3, 2), dtype=np.uint64)
+        n = cam.samples_per_pixel if sample_count is None else sample_count
+        rc = self.L.oracle_render_fixed_words(words.ctypes.data, width, height, rt.Rect(*[int(v) for v in region]), C.byref(cam), spheres.ctypes.data,
+                                              len(spheres), materials.ctypes.data, len(materials), seed, sample_begin, n, threads)
+        assert rc == 0
+        return words
 
     def ray_sphere_intersection(self, precision, o, d, c, radius, t_min, t_max):
         o, d, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (o, d, c))

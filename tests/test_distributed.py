@@ -18,7 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPP = 5
 
 
-def _worker(rank, world_size, partition, weak, width, port, out_path):
+def _fixed_words_to_mean(words, total_samples):
+    """(.., 2) uint64 accumulator words of RT_PRECISION_MIXED_FIXED -> the sum a * 2^-32 + b * 2^-64 rounded to f64 once, times 1/spp"""
+    from fractions import Fraction
+    a = words[..., 0].astype(np.uint64).astype(object)
+    b = words[..., 1].astype(np.uint64).astype(object)
+    total = a * (1 << 32) + b
+    return np.vectorize(lambda t: float(Fraction(t, 1 << 64)), otypes=[np.float64])(total) * (1.0 / float(total_samples))
+
+
+def _worker(rank, world_size, partition, weak, width, port, out_path, mode="f32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,7 +41,7 @@ def _worker(rank, world_size, partition, weak, width, port, out_path):
     cam = rt.calculate_camera_render_data(cs)
     w, h = cs.image_width, cs.image_height
     plan = mg.Plan(partition, rank, world_size, SPP, weak=weak)
-    accum = torch.zeros(h, w, 3, dtype=torch.int64)
+    accum = torch.zeros((h, w, 3, 2) if mode == "mixed-fixed" else (h, w, 3), dtype=torch.int64)
     image = torch.zeros(h, w, 3, dtype=torch.float64)
     gathered = torch.zeros_like(image)
 
@@ -40,10 +49,20 @@ def _worker(rank, world_size, partition, weak, width, port, out_path):
         for v in range(h):
             if (v // strip_rows) % strip_count != strip_index or sample_count == 0:
                 continue
+            if mode == "mixed-fixed":
+                words = o.render_fixed_words(w, h, (0, v, w, v + 1), cam, sph, mat, seed=4, sample_begin=sample_begin, sample_count=sample_count)
+                buf[v] = torch.from_numpy(words[v].view(np.int64))
+                continue
             r = o.render_region(w, h, (0, v, w, v + 1), cam, sph, mat, precision=rt.PRECISION_F32, seed=4, sample_begin=sample_begin, sample_count=sample_count)
             buf[v] = torch.from_numpy(r["accum"][v].astype(np.int64))
 
     def finish(buf, img, total_samples, strip_rows, strip_index, strip_count):
+        if mode == "mixed-fixed":
+            mean = _fixed_words_to_mean(buf.numpy().view(np.uint64), total_samples)
+            for v in range(h):
+                if (v // strip_rows) % strip_count == strip_index:
+                    img[v] = torch.from_numpy(np.sqrt(mean[v]))
+            return
         q = buf.numpy().astype(np.uint64)
         as_f64 = (q >> np.uint64(32)).astype(np.float64) * 4294967296.0 + (q & np.uint64(0xFFFFFFFF)).astype(np.float64)
         mean = (as_f64 * (1.0 / 4294967296.0)) * (1.0 / float(total_samples))
@@ -75,6 +94,23 @@ def test_ranks_equal_one(rt, oracle, tmp_path, partition, weak, world_size, widt
     assert h % 8 != 0
     total = SPP * world_size if weak else SPP
     ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F32, seed=4, sample_count=total)
+    assert np.array_equal(got, ref["image"])
+
+
+@pytest.mark.parametrize("world_size,width", [(2, 40), (3, 40)])
+@pytest.mark.parametrize("partition,weak", [("rows", False), ("samples", False), ("samples", True)])
+def test_ranks_equal_one_with_fixed_point_f64_sums(rt, oracle, tmp_path, partition, weak, world_size, width):
+    """RT_PRECISION_MIXED_FIXED: the Q32.64 words of the ranks' shares are added by the all-reduce (integers: exact,
+    whatever the split), so the N-way frame is bitwise the one-way frame of all the samples"""
+    out = str(tmp_path / "frame.npy")
+    port = 31200 + (os.getpid() * 7 + world_size * 31 + width + (0 if partition == "rows" else 97) + (53 if weak else 0)) % 1500
+    mp.spawn(_worker, args=(world_size, partition, weak, width, port, out, "mixed-fixed"), nprocs=world_size, join=True)
+    got = np.load(out)
+    cs, sph, mat = rt.build_dev_scene(width)
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    total = SPP * world_size if weak else SPP
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED_FIXED, seed=4, sample_count=total)
     assert np.array_equal(got, ref["image"])
 
 

@@ -29,6 +29,7 @@ def gpu_render(rt, cs, cam, sph, mat, region=None, **kw):
     image = np.full((h, w, 3), -7.0)
     linear = np.full((h, w, 3), -7.0)
     region = (0, 0, w, h) if region is None else region
+    kw.setdefault("precision", rt.PRECISION_F32)  # the tests that name no precision were written for the throughput mode
     stats = rt.render_region(image, region, cam, sph, mat, linear_out=linear, want_stats=True, **kw)
     return image, linear, stats
 
@@ -166,21 +167,21 @@ def test_device_resident_strips_and_sample_split(rt, oracle):
     world = rt.World(sph, mat)
     dev = torch.device("cuda:0")
     full = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)  # Q32.32 sums of the f32 throughput mode
-    world.render_accumulate(cam, w, h, full.data_ptr(), seed=8, sample_chunks=1)
+    world.render_accumulate(cam, w, h, full.data_ptr(), seed=8, sample_chunks=1, precision=rt.PRECISION_F32)
     torch.cuda.synchronize()
     ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=8)
     assert np.array_equal(full.cpu().numpy().astype(np.float64), ref["accum"])
     # row strips dealt over 3 "ranks" tile the image exactly
     parts = torch.full((h, w, 3), -1, dtype=torch.int64, device=dev)
     for r in range(3):
-        world.render_accumulate(cam, w, h, parts.data_ptr(), seed=8, strip_rows=16, strip_index=r, strip_count=3, sample_chunks=1)
+        world.render_accumulate(cam, w, h, parts.data_ptr(), seed=8, strip_rows=16, strip_index=r, strip_count=3, sample_chunks=1, precision=rt.PRECISION_F32)
     torch.cuda.synchronize()
     assert torch.equal(parts, full)
     # sample split: [0,2) + [2,6) traced separately are the same paths
     a = torch.zeros_like(full)
     b = torch.zeros_like(full)
-    world.render_accumulate(cam, w, h, a.data_ptr(), seed=8, sample_begin=0, sample_count=2, sample_chunks=1)
-    world.render_accumulate(cam, w, h, b.data_ptr(), seed=8, sample_begin=2, sample_count=4, sample_chunks=1)
+    world.render_accumulate(cam, w, h, a.data_ptr(), seed=8, sample_begin=0, sample_count=2, sample_chunks=1, precision=rt.PRECISION_F32)
+    world.render_accumulate(cam, w, h, b.data_ptr(), seed=8, sample_begin=2, sample_count=4, sample_chunks=1, precision=rt.PRECISION_F32)
     torch.cuda.synchronize()
     ra = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=8, sample_begin=0, sample_count=2)
     rb = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=0, seed=8, sample_begin=2, sample_count=4)
@@ -189,7 +190,7 @@ def test_device_resident_strips_and_sample_split(rt, oracle):
     assert torch.equal(a + b, full)  # exact sums: any split of the samples adds up to the same accumulators
     # finalize on the device
     img = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
-    world.finalize(full.data_ptr(), w, h, 6, img.data_ptr())
+    world.finalize(full.data_ptr(), w, h, 6, img.data_ptr(), precision=rt.PRECISION_F32)
     torch.cuda.synchronize()
     assert np.array_equal(img.cpu().numpy(), ref["image"])
     assert world.last_kernel_ns() > 0
@@ -256,7 +257,7 @@ def test_stochastic_mode_noise_band(rt, oracle):
     w, h = cs.image_width, cs.image_height
     converged = np.zeros((h, w, 3))
     lin_conv = np.zeros((h, w, 3))
-    rt.render_region(converged, (0, 0, w, h), cam, sph, mat, seed=1234, linear_out=lin_conv)
+    rt.render_region(converged, (0, 0, w, h), cam, sph, mat, seed=1234, linear_out=lin_conv, precision=rt.PRECISION_F32)
     cs.samples_per_pixel = 64
     cam = rt.calculate_camera_render_data(cs)
 
@@ -266,7 +267,7 @@ def test_stochastic_mode_noise_band(rt, oracle):
     gpu = []
     for k in range(4):
         img, lin = np.zeros((h, w, 3)), np.zeros((h, w, 3))
-        rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=50 + k, rng_mode=rt.RNG_STOCHASTIC, linear_out=lin)
+        rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=50 + k, rng_mode=rt.RNG_STOCHASTIC, linear_out=lin, precision=rt.PRECISION_F32)
         gpu.append(rmse(lin))
     cpu = [rmse(oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=900 + k, threads=8)["linear"]) for k in range(3)]
     print("RMSE vs converged: GPU f32 stochastic", gpu, "CPU f64 restatement", cpu)
@@ -276,7 +277,7 @@ def test_stochastic_mode_noise_band(rt, oracle):
     cs.samples_per_pixel = 256
     cam4 = rt.calculate_camera_render_data(cs)
     img, lin = np.zeros((h, w, 3)), np.zeros((h, w, 3))
-    rt.render_region(img, (0, 0, w, h), cam4, sph, mat, seed=77, linear_out=lin)
+    rt.render_region(img, (0, 0, w, h), cam4, sph, mat, seed=77, linear_out=lin, precision=rt.PRECISION_F32)
     assert 0.4 < rmse(lin) / np.mean(gpu) < 0.62
 
 
@@ -307,9 +308,9 @@ def test_device_ppm_strips_and_extremes(rt):
     accum = torch.from_numpy(q).to(dev)
     text = torch.zeros(cs.image_height * w * 12, dtype=torch.uint8, device=dev)
     for r in range(2):
-        world.finalize_ppm(accum.data_ptr(), w, cs.image_height, spp, text.data_ptr(), strip_rows=8, strip_index=r, strip_count=2)
+        world.finalize_ppm(accum.data_ptr(), w, cs.image_height, spp, text.data_ptr(), strip_rows=8, strip_index=r, strip_count=2, precision=rt.PRECISION_F32)
     img = torch.zeros(cs.image_height, w, 3, dtype=torch.float64, device=dev)
-    world.finalize(accum.data_ptr(), w, cs.image_height, spp, img.data_ptr())
+    world.finalize(accum.data_ptr(), w, cs.image_height, spp, img.data_ptr(), precision=rt.PRECISION_F32)
     torch.cuda.synchronize()
     body = rt.serialize_ppm(img.cpu().numpy()).split(b"255\n", 1)[1]
     assert bytes(text.cpu().numpy()) == body
@@ -409,7 +410,7 @@ def test_concurrent_calls_from_host_threads(rt):
 
     def work(rect):
         try:
-            rt.render_region(image, rect, cam, sph, mat, seed=31)
+            rt.render_region(image, rect, cam, sph, mat, seed=31, precision=rt.PRECISION_F32)
         except Exception as e:  # noqa: BLE001 - reported below
             errors.append(e)
 
@@ -439,7 +440,7 @@ def test_in_process_multi_device_strips(rt, count, monkeypatch):
     a, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=14, region=region)
     b, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=14, region=region, device=0, device_count=count)
     assert np.array_equal(a, b)
-    text = rt.render_ppm(w, h, cam, sph, mat, seed=14, device=0, device_count=count)
+    text = rt.render_ppm(w, h, cam, sph, mat, seed=14, device=0, device_count=count, precision=rt.PRECISION_F32)
     assert text == rt.serialize_ppm(one)
 
 
@@ -527,7 +528,7 @@ def test_extreme_shapes(rt, oracle):
     cam = rt.calculate_camera_render_data(cs)
     ref = oracle.render_region(1, 1, (0, 0, 1, 1), cam, sph, mat, precision=0, seed=5)
     image = np.zeros((1, 1, 3))
-    rt.render_region(image, (0, 0, 1, 1), cam, sph, mat, seed=5)
+    rt.render_region(image, (0, 0, 1, 1), cam, sph, mat, seed=5, precision=rt.PRECISION_F32)
     assert np.array_equal(image, ref["image"])
     cs, cam, sph, mat = scene(rt, "dev", 40, 1)
     w, h = cs.image_width, cs.image_height
@@ -561,11 +562,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields(monkeypatch, capsys
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["verified"] is True
-    assert d["config"]["precision"] in ("f32", "mixed", "f64") and d["dtype"] == {"f32": "f32", "mixed": "f64 (f32 candidate filter)", "f64": "f64"}[d["config"]["precision"]]
+    assert d["config"]["precision"] == "mixed-fixed" and d["dtype"] == "f64 (f32 candidate filter)"
+    assert "bitwise = True" in d["verified_against"] and "100.0000 %" in d["verified_against"]
     # the other arithmetic modes are timed beside the headline one, each with the parity criteria it meets
-    assert set(d["modes"]) == {"f32", "mixed", "f64"} and all(m["value"] > 0 and m["parity"] for m in d["modes"].values())
-    assert d["modes"]["f32"]["verified"] is True and d["modes"][d["config"]["precision"]]["verified"] is True
+    assert set(d["modes"]) == {"f32", "mixed", "mixed-fixed", "f64"} and all(m["value"] > 0 and m["parity"] for m in d["modes"].values())
+    assert all(d["modes"][k]["verified"] is True for k in ("f32", "mixed", "mixed-fixed"))
     assert d["roofline"]["traffic_source"] and d["roofline"]["algorithmic_bytes"] > 0
+    assert d["roofline"]["traffic_model"] == 160 * 90 * 8 * 48 + 160 * 90 * 48 + 16 * int(d["config"]["workload"].split("(")[1].split()[0])
+    assert d["roofline"]["executed_flop_per_test"] == 14 and abs(d["roofline"]["frac_executed"] * 17 - d["roofline"]["frac"] * 14) < 1e-12
+    assert len(d["roofline"]["kernel_source_sha16"]) == 16
     r = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.0 < r["frac"] < 1.0 and d["value"] > 0
@@ -757,9 +762,9 @@ def test_config4_final_scene_3840x2160_over_eight_devices(rt, oracle, monkeypatc
     w, h = cs.image_width, cs.image_height
     assert (w, h) == (3840, 2160)
     one = np.zeros((h, w, 3))
-    st_one = rt.render_region(one, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True)
+    st_one = rt.render_region(one, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True, precision=rt.PRECISION_F32)
     many = np.zeros((h, w, 3))
-    st_many = rt.render_region(many, (0, 0, w, h), cam, sph, mat, seed=1, device=0, device_count=8, want_stats=True)
+    st_many = rt.render_region(many, (0, 0, w, h), cam, sph, mat, seed=1, device=0, device_count=8, want_stats=True, precision=rt.PRECISION_F32)
     assert np.array_equal(one, many)
     assert int(st_one[0]) == int(st_many[0]) and int(st_many[rt.STAT_SAMPLES]) == w * h * 2
     win = (1900, 1400, 1932, 1416)
@@ -777,7 +782,7 @@ def test_config4_final_scene_3840x2160_over_eight_devices(rt, oracle, monkeypatc
 # ---------------------------------------------------------------------------------------------------
 # several calls in flight on one world
 
-@pytest.mark.parametrize("precision,chunks", [(0, 0), (1, 3), (3, 0)])
+@pytest.mark.parametrize("precision,chunks", [(0, 0), (1, 3), (3, 0), (4, 0)])
 def test_two_streams_on_one_world(rt, precision, chunks):
     """rt_render_accumulate from two streams on ONE world at the same time: every call has its own queue head, and
     calls that share the world's scratch buffer are ordered on the device.  The results are those of the calls
@@ -787,25 +792,26 @@ def test_two_streams_on_one_world(rt, precision, chunks):
     w, h = cs.image_width, cs.image_height
     world = rt.World(sph, mat)
     dev = torch.device("cuda:0")
-    dtype = torch.int64 if precision == 0 else torch.float64
+    dtype = torch.int64 if precision in (0, 4) else torch.float64
     kw = dict(precision=precision, sample_chunks=chunks)
-    want_a = torch.zeros(h, w, 3, dtype=dtype, device=dev)
-    want_b = torch.zeros(h, w, 3, dtype=dtype, device=dev)
+    shape = (h, w, 3, 2) if precision == 4 else (h, w, 3)   # Q32.64: two words per channel
+    want_a = torch.zeros(shape, dtype=dtype, device=dev)
+    want_b = torch.zeros(shape, dtype=dtype, device=dev)
     world.render_accumulate(cam, w, h, want_a.data_ptr(), seed=1, **kw)
     torch.cuda.synchronize()
     world.render_accumulate(cam, w, h, want_b.data_ptr(), seed=2, sample_begin=3, sample_count=9, **kw)
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     for attempt in range(3):
-        got_a = torch.full((h, w, 3), -1, dtype=dtype, device=dev)
-        got_b = torch.full((h, w, 3), -1, dtype=dtype, device=dev)
+        got_a = torch.full(shape, -1, dtype=dtype, device=dev)
+        got_b = torch.full(shape, -1, dtype=dtype, device=dev)
         torch.cuda.synchronize()
         world.render_accumulate(cam, w, h, got_a.data_ptr(), seed=1, stream=s1.cuda_stream, **kw)   # long
         world.render_accumulate(cam, w, h, got_b.data_ptr(), seed=2, sample_begin=3, sample_count=9, stream=s2.cuda_stream, **kw)  # short, overlaps
         torch.cuda.synchronize()
         assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b), attempt
     # more calls in flight than the world has slots: the ninth waits for the first
-    outs = [torch.zeros(h, w, 3, dtype=dtype, device=dev) for _ in range(10)]
+    outs = [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(10)]
     for k, o in enumerate(outs):
         world.render_accumulate(cam, w, h, o.data_ptr(), seed=2, sample_begin=3, sample_count=9, stream=(s1 if k % 2 else s2).cuda_stream, **kw)
     torch.cuda.synchronize()
@@ -841,10 +847,10 @@ def test_one_shot_calls_reuse_and_replace_what_they_cache(rt, oracle):
     assert np.array_equal(big, refb["image"])
     image, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=3)
     assert np.array_equal(image, ref["image"])
-    assert rt.render_ppm(w, h, cam, sph, mat, seed=3) == rt.serialize_ppm(ref["image"])
+    assert rt.render_ppm(w, h, cam, sph, mat, seed=3, precision=rt.PRECISION_F32) == rt.serialize_ppm(ref["image"])
     rt.release_cache()
     image = np.zeros((h, w, 3))
-    rt.render_region(image, (0, 0, w, h), cam, sph, mat, seed=3)   # without linear_out this time
+    rt.render_region(image, (0, 0, w, h), cam, sph, mat, seed=3, precision=rt.PRECISION_F32)   # without linear_out this time
     assert np.array_equal(image, ref["image"])
 
 
@@ -896,15 +902,15 @@ def test_mixed_equals_f64_kernel_on_adversarial_worlds(rt, block):
         assert np.array_equal(lin_b, lin_d) and np.array_equal(b, d) and int(st_b[0]) == int(st_d[0]), ("hierarchy", block, case, scale, dist)
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2, 3])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3, 4])
 def test_zero_samples_overwrite_with_zero(rt, precision):
     """rt_render_accumulate overwrites its pixels with the sum of its samples' colours: of no samples, zero"""
     import torch
     cs, cam, sph, mat = scene(rt, "dev", 40, 1)
     w, h = cs.image_width, cs.image_height
     world = rt.World(sph, mat)
-    dtype = {0: torch.int64, 1: torch.float64, 2: torch.float32, 3: torch.float64}[precision]
-    acc = torch.full((h, w, 3), 7, dtype=dtype, device="cuda:0")
+    dtype = {0: torch.int64, 1: torch.float64, 2: torch.float32, 3: torch.float64, 4: torch.int64}[precision]
+    acc = torch.full((h, w, 3) + ((2,) if precision == 4 else ()), 7, dtype=dtype, device="cuda:0")
     world.render_accumulate(cam, w, h, acc.data_ptr(), precision=precision, sample_begin=3, sample_count=0, region=(8, 8, 32, 16))
     torch.cuda.synchronize()
     assert bool((acc[8:16, 8:32] == 0).all()) and bool((acc[:8] == 7).all()) and bool((acc[16:] == 7).all())
@@ -934,3 +940,137 @@ def test_many_candidates_per_ray_overflow_the_wave_queue(rt, oracle, precision):
     image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=8, precision=precision)
     assert np.array_equal(image, ref["image"]) and np.array_equal(linear, ref["linear"])
     assert int(stats[0]) == int(ref["stats"][0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# RT_PRECISION_MIXED_FIXED: the mixed mode's f64 paths, sample colours added exactly in Q32.64
+
+def words_to_sum(acc):
+    """(h, w, 3, 2) int64 words -> exact Python integers in units of 2^-64"""
+    a = acc[..., 0].astype(np.uint64).astype(object)
+    b = acc[..., 1].astype(np.uint64).astype(object)
+    return a * (1 << 32) + b
+
+
+@pytest.mark.parametrize("name,width,spp", [("two", 64, 8), ("dev", 64, 8), ("dev", 200, 3), ("final", 96, 4)])
+def test_mixed_fixed_against_the_oracle_and_the_f64_criteria(rt, oracle, name, width, spp):
+    """bitwise the oracle's statement of the same sums; against the reference's sequential f64 sums: within 1e-12
+    relative per linear pixel and every 8-bit pixel identical (the spec asks for 1e-4 and 99.9 %)"""
+    cs, cam, sph, mat = scene(rt, name, width, spp)
+    w, h = cs.image_width, cs.image_height
+    image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=11, precision=rt.PRECISION_MIXED_FIXED)
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED_FIXED, seed=11, threads=4)
+    ref64 = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=11, threads=4)
+    assert int(stats[rt.STAT_SEGMENTS]) == int(ref["stats"][rt.STAT_SEGMENTS]) == int(ref64["stats"][rt.STAT_SEGMENTS])
+    assert np.array_equal(linear, ref["linear"]) and np.array_equal(image, ref["image"])
+    lit = ref64["linear"] > 1e-7
+    assert np.all(np.abs(linear[lit] - ref64["linear"][lit]) <= 1e-12 * ref64["linear"][lit])
+    assert np.all(np.abs(linear[~lit] - ref64["linear"][~lit]) <= 1e-19)
+    assert np.array_equal(rt.quantize_rgb8(image), rt.quantize_rgb8(ref64["image"]))
+    assert rt.render_ppm(w, h, cam, sph, mat, seed=11, precision=rt.PRECISION_MIXED_FIXED) == oracle.serialize_ppm(ref["image"])
+    for fetch in (rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
+        b_image, b_linear, b_stats = gpu_render(rt, cs, cam, sph, mat, seed=11, precision=rt.PRECISION_MIXED_FIXED, sphere_fetch=fetch)
+        assert np.array_equal(b_linear, linear) and np.array_equal(b_image, image), fetch
+        assert int(b_stats[rt.STAT_SEGMENTS]) == int(stats[rt.STAT_SEGMENTS])
+
+
+def test_mixed_fixed_sums_are_exact_and_split_anywhere(rt, oracle):
+    """the accumulator words hold the exact sum of the samples' colours truncated at 2^-64 (checked with Python integers
+    against the colours of the ordered mode, one sample per call), and any split of the samples or the pixels over calls
+    adds up to the words of one call"""
+    import torch
+    from fractions import Fraction
+    cs, cam, sph, mat = scene(rt, "dev", 48, 7)
+    w, h = cs.image_width, cs.image_height
+    world = rt.World(sph, mat)
+    dev = torch.device("cuda:0")
+    whole = torch.full((h, w, 3, 2), -1, dtype=torch.int64, device=dev)
+    world.render_accumulate(cam, w, h, whole.data_ptr(), seed=5, precision=rt.PRECISION_MIXED_FIXED)
+    torch.cuda.synchronize()
+    total = words_to_sum(whole.cpu().numpy())
+    # every sample's f64 colour on its own, from the ordered mode
+    exact = np.zeros((h, w, 3), dtype=object)
+    one = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+    for s_ in range(7):
+        world.render_accumulate(cam, w, h, one.data_ptr(), seed=5, precision=rt.PRECISION_MIXED, sample_begin=s_, sample_count=1)
+        torch.cuda.synchronize()
+        col = one.cpu().numpy()
+        assert np.all((col >= 0) & (col < 2.0 ** 32))
+        exact += np.vectorize(lambda x: int(Fraction(x) * (1 << 64)), otypes=[object])(col)   # floor: x >= 0
+    assert np.array_equal(total, exact)
+    assert np.array_equal(total, words_to_sum(oracle.render_fixed_words(w, h, (0, 0, w, h), cam, sph, mat, seed=5).view(np.int64)))
+    # the finalised mean is that sum rounded once, times 1/spp; the image its square root
+    img = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+    lin = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+    world.finalize(whole.data_ptr(), w, h, 7, img.data_ptr(), precision=rt.PRECISION_MIXED_FIXED, d_linear=lin.data_ptr())
+    torch.cuda.synchronize()
+    want = np.vectorize(lambda t: float(Fraction(t, 1 << 64)) * (1.0 / 7.0), otypes=[np.float64])(exact)
+    assert np.array_equal(lin.cpu().numpy(), want) and np.array_equal(img.cpu().numpy(), np.sqrt(want))
+    # samples [0, 3) + [3, 7); three strip sets; a ragged region
+    a = torch.zeros_like(whole); b = torch.zeros_like(whole)
+    world.render_accumulate(cam, w, h, a.data_ptr(), seed=5, precision=rt.PRECISION_MIXED_FIXED, sample_begin=0, sample_count=3)
+    world.render_accumulate(cam, w, h, b.data_ptr(), seed=5, precision=rt.PRECISION_MIXED_FIXED, sample_begin=3, sample_count=4)
+    torch.cuda.synchronize()
+    # (the words themselves are not unique -- a lane carries its low word into the high one per unit of work -- the sums are)
+    assert np.array_equal(words_to_sum(a.cpu().numpy()) + words_to_sum(b.cpu().numpy()), total)
+    assert np.array_equal(words_to_sum((a + b).cpu().numpy()), total)          # what an all-reduce over two ranks forms
+    strips = torch.full_like(whole, -1)
+    for r in range(3):
+        world.render_accumulate(cam, w, h, strips.data_ptr(), seed=5, precision=rt.PRECISION_MIXED_FIXED, strip_rows=8, strip_index=r, strip_count=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(words_to_sum(strips.cpu().numpy()), total)
+    part = torch.full_like(whole, -1)
+    world.render_accumulate(cam, w, h, part.data_ptr(), seed=5, precision=rt.PRECISION_MIXED_FIXED, region=(3, 5, 41, 22))
+    torch.cuda.synchronize()
+    assert np.array_equal(words_to_sum(part[5:22, 3:41].cpu().numpy()), total[5:22, 3:41]) and bool((part[:5] == -1).all()) and bool((part[:, 41:] == -1).all())
+    world.close()
+
+
+def test_mixed_fixed_outside_the_filter_range(rt, oracle):
+    """a world the filter's error bound does not cover keeps every sphere of every ray: still the f64 paths"""
+    cs, sph, mat = rt.build_dev_scene(48)
+    cs.samples_per_pixel = 3
+    for scale in (1e-7, 1e7):
+        s2 = sph.copy()
+        s2["center"] *= scale
+        s2["radius"] *= scale
+        c2 = rt.CameraSettings.from_buffer_copy(cs)
+        c2.position = rt.V3(cs.position.x * scale, cs.position.y * scale, cs.position.z * scale)
+        c2.focus_distance = cs.focus_distance * scale
+        cam = rt.calculate_camera_render_data(c2)
+        w, h = c2.image_width, c2.image_height
+        for fetch in (rt.FETCH_AUTO, rt.FETCH_BVH):
+            image, linear, stats = gpu_render(rt, c2, cam, s2, mat, seed=4, precision=rt.PRECISION_MIXED_FIXED, sphere_fetch=fetch)
+            ref = oracle.render_region(w, h, (0, 0, w, h), cam, s2, mat, precision=rt.PRECISION_MIXED_FIXED, seed=4, threads=4)
+            assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0]), (scale, fetch)
+
+
+def test_null_options_return_the_f64_reference_image(rt, oracle):
+    """rt_render_region(..., opts = NULL), straight through the C ABI as the Odin host's simplest call would be: the
+    default precision is the one whose image is the reference's f64 arithmetic (main.odin:19, :841), bit for bit"""
+    import ctypes as C
+    cs, cam, sph, mat = scene(rt, "dev", 200, 5)
+    w, h = cs.image_width, cs.image_height
+    assert (w, h) == (200, 112)
+    image = np.full((h, w, 3), -7.0)
+    rc = rt.lib().rt_render_region(image.ctypes.data, w, h, rt.Rect(0, 0, w, h), C.byref(cam), sph.ctypes.data, len(sph), mat.ctypes.data, len(mat), None)
+    assert rc == rt.RT_OK, rt.lib().rt_last_error()
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=0, threads=4)
+    assert np.array_equal(image, ref["image"])
+    o = rt.Options()
+    rt.lib().rt_options_default(C.byref(o))
+    assert (o.precision, o.rng_mode, o.device, o.device_count, o.flags, o.seed) == (rt.PRECISION_MIXED, rt.RNG_DETERMINISTIC, -1, 1, 0, 0)
+
+
+def test_staging_allocation_falls_back_to_a_smaller_window(rt, oracle, monkeypatch):
+    """the ordered mixed mode stages min(all samples, budget); when the device refuses that allocation the window is
+    halved until it fits (simulated: requests above 1 MiB fail), and the image does not change"""
+    cs, cam, sph, mat = scene(rt, "dev", 100, 37)      # 140 KB per staged sample: 5.2 MB for all 37
+    w, h = cs.image_width, cs.image_height
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=2, threads=8)
+    rt.release_cache()
+    monkeypatch.setenv("RT_MI355X_TEST_MALLOC_LIMIT_MIB", "1")
+    for _ in range(2):   # the second call starts from the size that fitted
+        image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=2, precision=rt.PRECISION_MIXED)
+        assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0])
+    rt.release_cache()

@@ -385,3 +385,27 @@ def test_sample_split_and_chunks_in_the_oracle(rt, oracle):
     mt = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=9, threads=4)
     st = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=1, seed=9, threads=1)
     assert np.array_equal(mt["image"], st["image"])
+
+
+def test_fixed_point_sums_of_the_mixed_mode(rt, oracle):
+    """RT_PRECISION_MIXED_FIXED in the oracle: the sum of the samples' f64 colours, each truncated at 2^-64, is exact and
+    rounded once (checked with Python rationals against the colours of single-sample renders); against the sequential
+    f64 sum of main.odin:575 it stays within 1e-12 relative"""
+    from fractions import Fraction
+    cs, sph, mat = rt.build_dev_scene(24)
+    cam = rt.calculate_camera_render_data(cs)
+    w, h = cs.image_width, cs.image_height
+    n = 9
+    fixed = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_MIXED_FIXED, seed=6, sample_count=n)
+    seq = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=6, sample_count=n)
+    exact = np.zeros((h, w, 3), dtype=object)
+    for s_ in range(n):
+        col = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64, seed=6, sample_begin=s_, sample_count=1)["accum"]
+        exact += np.vectorize(lambda x: int(Fraction(x) * (1 << 64)), otypes=[object])(col)
+    want = np.vectorize(lambda t: float(Fraction(t, 1 << 64)), otypes=[np.float64])(exact)
+    assert np.array_equal(fixed["accum"], want)
+    assert np.array_equal(fixed["linear"], want * (1.0 / n)) and np.array_equal(fixed["image"], np.sqrt(want * (1.0 / n)))
+    assert int(fixed["stats"][0]) == int(seq["stats"][0]) and int(fixed["stats"][6]) == 0
+    lit = seq["linear"] > 1e-7
+    assert np.all(np.abs(fixed["linear"][lit] - seq["linear"][lit]) <= 1e-12 * seq["linear"][lit])
+    assert np.array_equal(oracle.quantize_rgb8(fixed["image"]), oracle.quantize_rgb8(seq["image"]))

@@ -79,7 +79,7 @@ def test_static_scratch_limits_are_reported(rt):
     # the hierarchy must have been built by the allocating entry point
     q = torch.zeros(h, w, 3, dtype=torch.int64, device=dev)
     with pytest.raises(rt.RtError):
-        world.render_accumulate(cam, w, h, q.data_ptr(), sphere_fetch=rt.FETCH_BVH, static_scratch=True)
+        world.render_accumulate(cam, w, h, q.data_ptr(), sphere_fetch=rt.FETCH_BVH, static_scratch=True, precision=rt.PRECISION_F32)
     world.close()
     # a frame whose single staged sample exceeds the array: refused
     cs, cam, sph, mat = _scene(rt, 3840, 1)

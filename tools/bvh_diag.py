@@ -13,7 +13,7 @@ cs.samples_per_pixel = spp
 cam = rt.calculate_camera_render_data(cs)
 w, h = cs.image_width, cs.image_height
 img = np.zeros((h, w, 3))
-st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, sphere_fetch=rt.FETCH_BVH, want_stats=True)
+st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, sphere_fetch=rt.FETCH_BVH, want_stats=True, precision=rt.PRECISION_F32)
 seg, iters, nodes, tests, trips = (int(st[i]) for i in (0, 4, 5, 6, 7))
 print(f"{scene}: segments {seg}, wave iterations {iters}, boxes/segment {nodes / seg:.2f}, sphere tests/segment {tests / seg:.2f}, "
       f"traversal trips per wave iteration {trips / iters:.1f} (slowest lane) vs lane mean {nodes / seg:.1f}: lane efficiency {nodes / (64 * trips):.3f}, kernel {int(st[2]) / 1e6:.1f} ms")

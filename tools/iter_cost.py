@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cost of one wave iteration (one ray segment per lane: closest-hit scan + shading) of the list-scan kernel,
 in SIMD cycles at 2.4 GHz, for the library RT_MI355X_LIB selects.  With a diagnostic build (RT_DIAG_COUNTERS) also
-how often the scan leaves its straight-line code.   usage: tools/iter_cost.py [f32|mixed|f64] [spp]"""
+how often the scan leaves its straight-line code.   usage: tools/iter_cost.py [f32|mixed|mixed-fixed|f64] [spp]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,13 +10,13 @@ rt = importlib.import_module("raytracing-in-one-weekend_amd")
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 fetch = {"": rt.FETCH_AUTO, "bvh": rt.FETCH_BVH, "bvh-global": rt.FETCH_BVH_GLOBAL}[os.environ.get("AB_FETCH", "")]  # AB_FETCH=bvh: through the hierarchy
-precision = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "f64": rt.PRECISION_F64}[mode]
+precision = {"f32": rt.PRECISION_F32, "mixed": rt.PRECISION_MIXED, "mixed-fixed": rt.PRECISION_MIXED_FIXED, "f64": rt.PRECISION_F64}[mode]
 cs, sph, mat = rt.build_final_scene(1, 1200)
 cs.samples_per_pixel = spp
 cam = rt.calculate_camera_render_data(cs)
 w, h = cs.image_width, cs.image_height
 world = rt.World(sph, mat)
-acc = torch.zeros(h, w, 3, dtype=torch.int64 if mode == "f32" else torch.float64, device="cuda")
+acc = torch.zeros((h, w, 3, 2) if mode == "mixed-fixed" else (h, w, 3), dtype=torch.int64 if mode in ("f32", "mixed-fixed") else torch.float64, device="cuda")
 st = torch.zeros(8, dtype=torch.int64, device="cuda")
 best = None
 for k in range(4):

@@ -15,7 +15,7 @@ def run(label, mat):
     img = np.zeros((h, w, 3))
     best = None
     for _ in range(3):
-        st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True)
+        st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True, precision=rt.PRECISION_F32)
         ns, seg, iters = int(st[2]), int(st[0]), int(st[4])
         cyc = ns * 2.4 * 1024 / iters   # SIMD cycles per wave iteration at 2.4 GHz
         best = cyc if best is None else min(best, cyc)

@@ -11,7 +11,7 @@ cs.samples_per_pixel = spp
 cam = rt.calculate_camera_render_data(cs)
 w, h = cs.image_width, cs.image_height
 img = np.zeros((h, w, 3))
-rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1)
+rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, precision=rt.PRECISION_F32)
 rgb = rt.quantize_rgb8(img)
 raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
 def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)

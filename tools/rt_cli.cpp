@@ -2,7 +2,7 @@
 // through the C ABI -- build a scene, compute the camera, render, print a P3 PPM to stdout --
 // with the scene, size, sample count and seed selectable at run time.
 //   rt_cli [--scene dev|two|final|stress] [--width W] [--spp N] [--depth D] [--seed S]
-//          [--gpus G] [--precision f32|mixed|f64|f32-literal] [--stochastic] [--stats] [--host-ppm] [--rounds N] > out.ppm
+//          [--gpus G] [--precision mixed|mixed-fixed|f32|f64|f32-literal] [--stochastic] [--stats] [--host-ppm] [--rounds N] > out.ppm
 // --rounds N is bench_materials of the reference (main_test.odin:8-46, :72-81): N renders of the scene through
 // the one-shot entry point, the last image to stdout, and the reference's statistics line to stderr (its
 // "bytes" are pixels, main_test.odin:24).
@@ -18,7 +18,7 @@
 #include "../include/rt_mi355x.h"
 
 int main(int argc, char **argv) {
-    std::string scene = "dev", precision = "f32";
+    std::string scene = "dev", precision = "mixed";
     int64_t width = 0, spp = 0, depth = -1;
     uint64_t seed = 1;
     int gpus = 1;
@@ -61,7 +61,12 @@ int main(int argc, char **argv) {
     rt_options_default(&opts);
     opts.seed = seed;
     opts.rng_mode = stochastic ? RT_RNG_STOCHASTIC : RT_RNG_DETERMINISTIC;
-    opts.precision = precision == "f64" ? RT_PRECISION_F64 : precision == "mixed" ? RT_PRECISION_MIXED : precision == "f32-literal" ? RT_PRECISION_F32_LITERAL : RT_PRECISION_F32;
+    if (precision == "f64") opts.precision = RT_PRECISION_F64;
+    else if (precision == "mixed") opts.precision = RT_PRECISION_MIXED; // the library's default: the reference's f64 image
+    else if (precision == "mixed-fixed") opts.precision = RT_PRECISION_MIXED_FIXED;
+    else if (precision == "f32-literal") opts.precision = RT_PRECISION_F32_LITERAL;
+    else if (precision == "f32") opts.precision = RT_PRECISION_F32;
+    else { std::fprintf(stderr, "unknown precision %s\n", precision.c_str()); return 2; }
     opts.device_count = gpus;
     uint64_t stats[RT_STATS_COUNT] = {0};
     opts.stats = stats;
