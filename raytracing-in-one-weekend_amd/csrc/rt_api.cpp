@@ -516,12 +516,23 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         world->bvh_built = true;
     }
 
+    // The entry point that allocates nothing may be called while its stream is being captured into a HIP graph: such a
+    // call must not synchronise with the host or record the world's timing events (an event recorded during capture
+    // cannot be waited for or queried afterwards), and it needs no slot, since its queue head is the fixed one.
+    bool capturing = false;
+    if (src.fixed) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &status) == hipSuccess) capturing = status == hipStreamCaptureStatusActive;
+        else (void)hipGetLastError();
+    }
     // this call's slot: its own queue head and events; a slot is reused only after its last call has ended
     const int slot_index = static_cast<int>(world->n_calls % CALL_SLOTS);
-    CallSlot &slot = world->slots[slot_index];
-    if (slot.used) HIP_TRY(hipEventSynchronize(slot.ev_end));
-    ++world->n_calls;
-    uint32_t *queue = src.queue != nullptr ? src.queue : slot.queue;
+    CallSlot *slot = capturing ? nullptr : &world->slots[slot_index];
+    if (slot != nullptr) {
+        if (slot->used) HIP_TRY(hipEventSynchronize(slot->ev_end));
+        ++world->n_calls;
+    }
+    uint32_t *queue = src.queue != nullptr ? src.queue : slot->queue;
 
     rtk::RenderParams p{};
     p.bvh_nodes = world->bvh_nodes; p.bvh_spheres = world->bvh_spheres; p.bvh_n_nodes = world->bvh_n_nodes;
@@ -563,9 +574,11 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     r.accum = d_accum; r.slabs = work; r.slab_stride = slab_stride; r.chunks = chunks;
     r.words_per_pixel = mixed_fixed ? 6 : 3;
     r.width = p.width; r.min_x = p.min_x; r.min_y = p.min_y; r.max_x = p.max_x; r.max_y = p.max_y; r.map = p.map;
-    HIP_TRY(hipEventRecord(slot.ev_begin, st));
-    slot.used = true; // from here on something of this call may be in flight
-    world->last_slot = slot_index;
+    if (slot != nullptr) {
+        HIP_TRY(hipEventRecord(slot->ev_begin, st));
+        slot->used = true; // from here on something of this call may be in flight
+        world->last_slot = slot_index;
+    }
     if (mixed) {
         // samples in windows of what the staging buffer holds: trace a window (any order), then add its
         // colours to the accumulators in sample order
@@ -587,7 +600,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         HIP_TRY(rtk::launch_render(p, precision, fetch, chunks, world->resident_blocks, st));
         if (chunks > 1 && !queue_mode) HIP_TRY(rtk::launch_reduce(r, precision, st));
     }
-    HIP_TRY(hipEventRecord(slot.ev_end, st));
+    if (slot != nullptr) HIP_TRY(hipEventRecord(slot->ev_end, st));
     if (work != nullptr && !src.fixed) {
         HIP_TRY(hipEventRecord(world->slabs_done, st));
         world->slabs_busy = true;
