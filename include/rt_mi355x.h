@@ -52,12 +52,18 @@ typedef struct { rt_v3 center; double radius; int64_t material_index; } rt_spher
 #define RT_MATERIAL_METALLIC_FRESNEL 3
 /* The other two METAL_FRESNEL_KINDs of that block, which the reference does not select (main.odin:332):
  * kind 0, reflectance_schlick_approximation(cos, r0) with r0 from 1.0/1.27035 (main.odin:334-335, :111-122), and
- * kind 1, reflectance_hoffman_approximation(cos, r0, 0.5) (main.odin:337-339, :132-144).  The latter is built as the
- * cited papers define it, not as the reference's text reads: schlick's arguments in their declared order (the text
- * passes (r0, cos_i), :133) and the factors 7^7/6^6 and 49/6 as real quotients (the text writes 823543 / 46656 and
- * 49 / 6, which Odin evaluates as the integers 17 and 8, :142).  math.pow(x, 6) is ((x*x)*x)^2. */
+ * kind 1, reflectance_hoffman_approximation(cos, r0, 0.5) (main.odin:337-339, :132-144).
+ * RT_MATERIAL_METALLIC_HOFFMAN is kind 1 AS THE REFERENCE'S TEXT COMPUTES IT, so that a host built with
+ * METAL_FRESNEL_KIND = 1 gets the image of its own CPU path: the Schlick term is called with its arguments swapped,
+ * reflectance_schlick_approximation(r0, cos_i) (main.odin:133), i.e. cos + (1 - cos)(1 - r0)^5, and the factors
+ * 823543 / 46656 and 49 / 6 are untyped integer divisions, 17 and 8 (main.odin:142).
+ * RT_MATERIAL_METALLIC_HOFFMAN_PAPER is the approximation as the cited papers define it: Schlick's arguments in their
+ * declared order and the factors 7^7/6^6 and 49/6 as real quotients (with h = 0.5 the reflectance at cos = 1/7 is then
+ * exactly 0.5); no counterpart in the reference.  In both, math.pow(x, 6) -- core:math, not in the reference's
+ * checkout -- is taken as ((x*x)*x)^2.  No fixture of the reference covers kinds 0 and 1: parity unpinned. */
 #define RT_MATERIAL_METALLIC_SCHLICK 4
 #define RT_MATERIAL_METALLIC_HOFFMAN 5
+#define RT_MATERIAL_METALLIC_HOFFMAN_PAPER 6
 
 /* material :: struct {type: material_type, data: {albedo: v3, param1: f64}}
  * param1 = fuzz for metallic, refractive index for dielectric       main.odin:274-289 (40 B) */

@@ -365,19 +365,21 @@ template <class Real> inline Real reflectance_fresnel(Real cos_i, Real sin_i, Re
     r_p *= r_p;
     return (r_s + r_p) * Real(0.5);
 }
-/* reflectance_schlick_lazanyi_approximation  main.odin:132-134, with the arguments of the Schlick term in
- * their declared order (cos_i, r0) -- the reference's text passes (r0, cos_i).  math.pow is core:math (third party,
- * not in the checkout); for the only exponent used, 6, it is taken as ((x*x)*x)^2. */
-template <class Real> inline Real reflectance_schlick_lazanyi_approximation(Real cos_i, Real r0, Real a) {
+/* reflectance_schlick_lazanyi_approximation  main.odin:132-134.  LITERAL: as the reference's text reads, the Schlick
+ * term is called with (r0, cos_i) where the procedure declares (cos_i, r0); otherwise in declared order, as the cited
+ * paper has it.  math.pow is core:math (third party, not in the checkout); for the only exponent used, 6, it is
+ * taken as ((x*x)*x)^2. */
+template <class Real, bool LITERAL> inline Real reflectance_schlick_lazanyi_approximation(Real cos_i, Real r0, Real a) {
     const Real x = Real(1) - cos_i;
     const Real x2 = x * x, x3 = x2 * x;
-    return reflectance_schlick_approximation(cos_i, r0) - a * cos_i * (x3 * x3);
+    const Real schlick = LITERAL ? reflectance_schlick_approximation(r0, cos_i) : reflectance_schlick_approximation(cos_i, r0);
+    return schlick - a * cos_i * (x3 * x3);
 }
-/* reflectance_hoffman_approximation  main.odin:141-144, with 823543/46656 = 7^7/6^6 and 49/6 as real quotients (the
- * reference's untyped integer constants divide to 17 and 8) */
-template <class Real> inline Real reflectance_hoffman_approximation(Real cos_i, Real r0, Real h) {
-    const Real a = static_cast<Real>(823543.0 / 46656.0) * (r0 - h) + static_cast<Real>(49.0 / 6.0) * (Real(1) - r0);
-    return reflectance_schlick_lazanyi_approximation(cos_i, r0, a);
+/* reflectance_hoffman_approximation  main.odin:141-144.  LITERAL: 823543 / 46656 and 49 / 6 are divisions of untyped
+ * integer constants, 17 and 8; otherwise the real quotients 7^7/6^6 and 49/6 of the cited paper. */
+template <class Real, bool LITERAL> inline Real reflectance_hoffman_approximation(Real cos_i, Real r0, Real h) {
+    const Real a = (LITERAL ? Real(17) : static_cast<Real>(823543.0 / 46656.0)) * (r0 - h) + (LITERAL ? Real(8) : static_cast<Real>(49.0 / 6.0)) * (Real(1) - r0);
+    return reflectance_schlick_lazanyi_approximation<Real, LITERAL>(cos_i, r0, a);
 }
 /* metallic_proc  main.odin:315-353.  kind < 0: the USE_METAL_FRESNEL = false branch (:348-350); otherwise that flag
  * set with METAL_FRESNEL_KIND = kind: 2 is what the reference selects (:341-344), 0 (:334-335) and 1 (:337-339) are
@@ -397,7 +399,9 @@ inline scatter_result<Real> metallic_proc(const material_t<Real> &m, const ray_t
             reflection_factor = reflectance_fresnel<Real>(cos_theta, sin_theta, Real(1), static_cast<Real>(1.27035));
         } else {
             const Real r0 = reflectance_at_normal_incidence(static_cast<Real>(0.7871846341559413)); /* 1.0/1.27035 */
-            reflection_factor = kind == 0 ? reflectance_schlick_approximation(cos_theta, r0) : reflectance_hoffman_approximation(cos_theta, r0, Real(0.5));
+            reflection_factor = kind == 0 ? reflectance_schlick_approximation(cos_theta, r0)
+                              : kind == 1 ? reflectance_hoffman_approximation<Real, true>(cos_theta, r0, Real(0.5))    /* the reference's text */
+                                          : reflectance_hoffman_approximation<Real, false>(cos_theta, r0, Real(0.5)); /* kind 3: the cited paper's form */
         }
         const vec3<Real> one{Real(1), Real(1), Real(1)};
         attenuation = m.albedo * (Real(1) - reflection_factor) + one * reflection_factor; /* math.lerp(albedo, 1, t) */
@@ -434,6 +438,7 @@ inline scatter_result<Real> material_scatter(const material_t<Real> &m, const ra
     case RT_MATERIAL_METALLIC_FRESNEL: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 2);
     case RT_MATERIAL_METALLIC_SCHLICK: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 0);
     case RT_MATERIAL_METALLIC_HOFFMAN: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 1);
+    case RT_MATERIAL_METALLIC_HOFFMAN_PAPER: return metallic_proc<Real, FAST>(m, ray_in, hit, g, 3);
     default: return dielectric_proc<Real, FAST>(m, ray_in, hit, g);
     }
 }

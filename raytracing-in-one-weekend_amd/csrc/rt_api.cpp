@@ -137,7 +137,7 @@ int32_t validate_scene(const rt_sphere *spheres, int64_t n_spheres, const rt_mat
     if (n_spheres > (1 << 24) || n_materials > (1 << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 spheres or materials");
     for (int64_t i = 0; i < n_materials; ++i) {
         const rt_material &m = materials[i];
-        if (m.type < RT_MATERIAL_LAMBERTIAN || m.type > RT_MATERIAL_METALLIC_HOFFMAN) return fail(RT_ERR_INVALID_SCENE, "material %lld has unknown type %lld", (long long)i, (long long)m.type);
+        if (m.type < RT_MATERIAL_LAMBERTIAN || m.type > RT_MATERIAL_METALLIC_HOFFMAN_PAPER) return fail(RT_ERR_INVALID_SCENE, "material %lld has unknown type %lld", (long long)i, (long long)m.type);
         // make_metallic_data asserts 0 <= fuzz <= 1 (main.odin:280)
         if ((m.type == RT_MATERIAL_METALLIC || m.type >= RT_MATERIAL_METALLIC_FRESNEL) && !(0.0 <= m.param1 && m.param1 <= 1.0)) return fail(RT_ERR_INVALID_SCENE, "metallic material %lld has fuzz %g outside [0, 1]", (long long)i, m.param1);
         if (m.type == RT_MATERIAL_DIELECTRIC && !(m.param1 > 0.0) ) return fail(RT_ERR_INVALID_SCENE, "dielectric material %lld has refractive index %g <= 0", (long long)i, m.param1);

@@ -1095,10 +1095,12 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     dir = dir + m.w * ruv;
                     if (mtype >= 4) {
                         // USE_METAL_FRESNEL with METAL_FRESNEL_KIND 0 (type 4: Schlick, main.odin:334-335, :111-122) or 1
-                        // (type 5: Hoffman, :337-339, :132-144, with schlick's arguments in their declared order and the two
-                        // quotients as real numbers, 7^7/6^6 and 49/6, where the reference's text swaps the former and
-                        // divides integers in the latter).  1.0/1.27035 is a constant expression there, i.e. the exact
-                        // quotient rounded once; math.pow(x, 6) is taken as ((x*x)*x)^2.
+                        // (Hoffman, :337-339, :132-144).  Type 5 is kind 1 as the reference's text computes it: the Schlick
+                        // term with its arguments swapped (:133 passes (r0, cos_i)), cos + (1 - cos)(1 - r0)^5, and the
+                        // factors 823543 / 46656 and 49 / 6 as the integer quotients 17 and 8 (:142).  Type 6 is the
+                        // approximation of the cited papers: arguments in declared order, 7^7/6^6 and 49/6 as real numbers.
+                        // 1.0/1.27035 is a constant expression there, i.e. the exact quotient rounded once; math.pow(x, 6)
+                        // is taken as ((x*x)*x)^2.
                         Real cos_theta = dot(-normalize<Real, FMA>(rd), nrm);
                         cos_theta = min_std(cos_theta, Real(1));
                         const Real rel = static_cast<Real>(0.7871846341559413);
@@ -1106,8 +1108,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                         r0 *= r0;
                         const Real qq = Real(1) - cos_theta;
                         Real refl = r0 + (Real(1) - r0) * qq * qq * qq * qq * qq;
-                        if (mtype == 5) {
-                            const Real aa = static_cast<Real>(823543.0 / 46656.0) * (r0 - Real(0.5)) + static_cast<Real>(49.0 / 6.0) * (Real(1) - r0);
+                        if (mtype >= 5) {
+                            const bool paper = mtype == 6;
+                            const Real aa = (paper ? static_cast<Real>(823543.0 / 46656.0) : Real(17)) * (r0 - Real(0.5)) +
+                                            (paper ? static_cast<Real>(49.0 / 6.0) : Real(8)) * (Real(1) - r0);
+                            if (!paper) {
+                                const Real a1 = Real(1) - r0; // reflectance_schlick_approximation(cos_i := r0, r0 := cos_theta)
+                                refl = cos_theta + (Real(1) - cos_theta) * a1 * a1 * a1 * a1 * a1;
+                            }
                             const Real q2 = qq * qq, q3 = q2 * qq;
                             refl = refl - aa * cos_theta * (q3 * q3);
                         }

@@ -110,7 +110,8 @@ def main():
         ("metal fuzz 1 grazing (may absorb)", (1, (0.8, 0.6, 0.2), 1.0), (1.0, -0.05, 0.0), True),
         ("metal, Fresnel kind 2", (3, (0.7, 0.6, 0.5), 0.1), (0.3, -1.0, 0.2), True),
         ("metal, Schlick kind 0", (4, (0.7, 0.6, 0.5), 0.1), (0.3, -1.0, 0.2), True),
-        ("metal, Hoffman kind 1", (5, (0.7, 0.6, 0.5), 0.1), (1.0, -0.02, 0.3), True),
+        ("metal, Hoffman kind 1 as the reference's text computes it", (5, (0.7, 0.6, 0.5), 0.1), (1.0, -0.02, 0.3), True),
+        ("metal, Hoffman as the cited paper defines it", (6, (0.7, 0.6, 0.5), 0.1), (1.0, -0.02, 0.3), True),
         ("glass front face", (2, (0.0, 0.0, 0.0), 1.5), (0.3, -1.0, 0.2), True),
         ("glass back face, steep: total internal reflection", (2, (0.0, 0.0, 0.0), 1.5), (1.0, -0.2, 0.0), False),
         ("glass back face, shallow", (2, (0.0, 0.0, 0.0), 1.5), (0.1, -1.0, 0.0), False),

@@ -184,11 +184,11 @@ def material_scatter(material, ro, rd, hit_p, hit_n, front_face, gen):
         if is_near_zero(out):
             out = hit_n
         return (hit_p, out), albedo, True
-    if mtype in (1, 3, 4, 5):
+    if mtype in (1, 3, 4, 5, 6):
         out = normalize(reflect(rd, hit_n))
         out = vadd(out, smul(param1, random_unit_vector(gen)))
         attenuation = albedo
-        if mtype >= 3:  # USE_METAL_FRESNEL (main.odin:324-347): type 3 = METAL_FRESNEL_KIND 2, 4 = kind 0, 5 = kind 1
+        if mtype >= 3:  # USE_METAL_FRESNEL (main.odin:324-347): type 3 = METAL_FRESNEL_KIND 2, 4 = kind 0, 5 = kind 1 as written, 6 = kind 1 as the papers have it
             cos_theta = min(dot(neg(normalize(rd)), hit_n), 1.0)
             if mtype == 3:
                 sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
@@ -199,8 +199,13 @@ def material_scatter(material, ro, rd, hit_p, hit_n, front_face, gen):
                 r0 *= r0
                 x = 1.0 - cos_theta
                 t = r0 + (1.0 - r0) * x * x * x * x * x    # reflectance_schlick_approximation(cos_theta, r0), main.odin:119-122
-                if mtype == 5:                              # Hoffman (main.odin:132-144), arguments and constants as the papers have them
+                if mtype == 5:                              # Hoffman as main.odin:132-144 reads: schlick(r0, cos_i), integer quotients 17 and 8
+                    a1 = 1.0 - r0
+                    t = cos_theta + (1.0 - cos_theta) * a1 * a1 * a1 * a1 * a1
+                    a = 17.0 * (r0 - 0.5) + 8.0 * (1.0 - r0)
+                if mtype == 6:                              # Hoffman, arguments and constants as the papers have them
                     a = (823543.0 / 46656.0) * (r0 - 0.5) + (49.0 / 6.0) * (1.0 - r0)
+                if mtype >= 5:
                     x2 = x * x
                     x3 = x2 * x
                     t = t - a * cos_theta * (x3 * x3)

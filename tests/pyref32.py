@@ -246,7 +246,7 @@ def material_scatter(material, rd, hit_p, hit_n, front_face, g):
         if all(abs(x) <= F(1e-8) for x in out):
             out = hit_n
         return (hit_p, out), albedo, True
-    if mtype in (1, 3, 4, 5):
+    if mtype in (1, 3, 4, 5, 6):
         out = normalize(reflect(rd, hit_n))
         out = vadd(out, smul(param1, random_unit_vector(g)))
         attenuation = albedo
@@ -257,8 +257,13 @@ def material_scatter(material, rd, hit_p, hit_n, front_face, g):
             r0 = r0 * r0
             x = ONE - cos_theta
             t = r0 + (ONE - r0) * x * x * x * x * x
-            if mtype == 5:
+            if mtype == 5:   # as main.odin:133, :142 read: schlick(r0, cos_i), integer quotients 17 and 8
+                a1 = ONE - r0
+                t = cos_theta + (ONE - cos_theta) * a1 * a1 * a1 * a1 * a1
+                a = F(17.0) * (r0 - HALF) + F(8.0) * (ONE - r0)
+            if mtype == 6:   # as the cited papers define it
                 a = F(823543.0 / 46656.0) * (r0 - HALF) + F(49.0 / 6.0) * (ONE - r0)
+            if mtype >= 5:
                 x2 = x * x
                 x3 = x2 * x
                 t = t - a * cos_theta * (x3 * x3)

@@ -371,7 +371,7 @@ def test_bvh_edge_cases(rt):
             assert np.array_equal(a, b) and int(st_a[0]) == int(st_b[0])
 
 
-@pytest.mark.parametrize("mtype", [3, 4, 5])
+@pytest.mark.parametrize("mtype", [3, 4, 5, 6])
 @pytest.mark.parametrize("precision", [0, 1, 2, 3])
 def test_metal_fresnel_material_type(rt, oracle, precision, mtype):
     """RT_MATERIAL_METALLIC_FRESNEL / _SCHLICK / _HOFFMAN (the reference's USE_METAL_FRESNEL build with
@@ -392,7 +392,7 @@ def test_metal_fresnel_material_type(rt, oracle, precision, mtype):
             bvh, _, _ = gpu_render(rt, cs, cam, sph, mat, seed=6, sphere_fetch=rt.FETCH_BVH)
             assert np.array_equal(bvh, image)
     bad = mat.copy()
-    bad["type"][0] = 6
+    bad["type"][0] = 7
     with pytest.raises(rt.RtError):
         gpu_render(rt, cs, cam, sph, bad, seed=6)
 
@@ -864,7 +864,7 @@ def test_mixed_equals_f64_kernel_on_adversarial_worlds(rt, block):
         scale = 10.0 ** rng.uniform(-3.0, 4.0)
         n = int(rng.choice([3, 8, 33, 120]))
         mat = np.zeros(6, dtype=rt.MATERIAL_DTYPE)
-        mat["type"] = [0, 1, 2, 2, int(rng.choice([3, 4, 5])), 0]
+        mat["type"] = [0, 1, 2, 2, int(rng.choice([3, 4, 5, 6])), 0]
         mat["albedo"] = rng.uniform(0.1, 0.95, size=(6, 3))
         mat["param1"] = [0.0, rng.uniform(0.0, 1.0), 1.5, 1.0 / 1.5, rng.uniform(0.0, 0.4), 0.0]
         sph = np.zeros(n, dtype=rt.SPHERE_DTYPE)

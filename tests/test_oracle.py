@@ -51,7 +51,7 @@ def test_rng_streams_are_distinct_and_uniform(oracle):
     assert chi2 < 50.0  # 15 degrees of freedom: P(chi2 > 50) ~ 1e-5
 
 
-@pytest.mark.parametrize("mtype", [4, 5])
+@pytest.mark.parametrize("mtype", [4, 5, 6])
 def test_f32_metal_kinds_against_python_statement(rt, oracle, mtype):
     """types 4 and 5 in the f32 throughput arithmetic: oracle against tests/pyref32.py"""
     cs, sph, mat = rt.build_dev_scene(16)
@@ -138,31 +138,36 @@ def test_metal_fresnel_attenuation_closed_form(oracle):
 
 
 def test_metal_schlick_and_hoffman_closed_form(oracle):
-    """METAL_FRESNEL_KIND 0 and 1 (main.odin:333-339) as material types 4 and 5.  Normal incidence: both give
-    r0 = ((1 - 1/n)/(1 + 1/n))^2 (the Hoffman correction carries a factor (1 - cos)^6 = 0).  At cos = 1/7 the
+    """METAL_FRESNEL_KIND 0 and 1 (main.odin:333-339) as material types 4 (Schlick), 5 (Hoffman as the reference's text
+    computes it) and 6 (Hoffman as the cited paper defines it).  Normal incidence: 4 and 6 give
+    r0 = ((1 - 1/n)/(1 + 1/n))^2 (the Hoffman correction carries a factor (1 - cos)^6 = 0); 5 gives 1, because the text
+    calls the Schlick term with (r0, cos_i) swapped (main.odin:133): cos + (1 - cos)(1 - r0)^5.  At cos = 1/7 the
     Lazanyi/Hoffman term peaks: Schlick minus a*cos*(1-cos)^6 with a = 7^7/6^6 (r0 - 0.5) + 49/6 (1 - r0), which
     for h = 0.5 makes the reflectance there exactly h -- that is the construction of Hoffman's paper, and it only
-    comes out with real quotients (the reference's integer 17 and 8 give another number)."""
+    comes out with real quotients; the text's integer quotients 17 and 8 (main.odin:142) give what type 5 returns."""
     albedo = (0.8, 0.6, 0.2)
     rel = 100000.0 / 127035.0
     r0 = ((1.0 - rel) / (1.0 + rel)) ** 2
     lerp = lambda t: [a * (1 - t) + t for a in albedo]
     for precision, tol in ((1, 1e-15), (0, 2e-6), (2, 2e-6)):
-        for mtype in (4, 5):
+        for mtype in (4, 5, 6):
             _, _, att, ok = oracle.material_scatter(precision, (mtype, albedo, 0.0), (0, 2, 0), (0.0, -1.0, 0.0), (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
-            assert ok and np.allclose(att, lerp(r0), rtol=0, atol=tol), (precision, mtype)
+            assert ok and np.allclose(att, lerp(1.0 if mtype == 5 else r0), rtol=0, atol=tol), (precision, mtype)
         c = 1.0 / 7.0
         d = (math.sqrt(1.0 - c * c), -c, 0.0)   # unit direction whose cosine with the normal (0, 1, 0) is 1/7
         schlick = r0 + (1.0 - r0) * (1.0 - c) ** 5
         _, _, att, _ = oracle.material_scatter(precision, (4, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
         assert np.allclose(att, lerp(schlick), rtol=0, atol=tol)
-        _, _, att, _ = oracle.material_scatter(precision, (5, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        _, _, att, _ = oracle.material_scatter(precision, (6, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
         assert np.allclose(att, lerp(0.5), rtol=0, atol=max(tol, 1e-12))
-        a_int = 17 * (r0 - 0.5) + 8 * (1.0 - r0)   # what the reference's integer quotients would give: not 0.5
-        assert abs((schlick - a_int * c * (1.0 - c) ** 6) - 0.5) > 1e-3
+        a_int = 17 * (r0 - 0.5) + 8 * (1.0 - r0)   # the reference's integer quotients
+        literal = (c + (1.0 - c) * (1.0 - r0) ** 5) - a_int * c * (1.0 - c) ** 6   # and its swapped Schlick arguments
+        assert abs(literal - 0.5) > 1e-3
+        _, _, att, _ = oracle.material_scatter(precision, (5, albedo, 0.0), (0, 2, 0), d, (0, 0, 0), (0.0, 1.0, 0.0), True, 1, 2, 3, 4)
+        assert np.allclose(att, lerp(literal), rtol=0, atol=max(tol, 1e-12))
 
 
-@pytest.mark.parametrize("mtype", [3, 4, 5])
+@pytest.mark.parametrize("mtype", [3, 4, 5, 6])
 def test_metal_fresnel_render_against_pyref(rt, oracle, mtype):
     """the three-material scene with its gold switched to a Fresnel variant: f64 oracle = pure-Python restatement"""
     cs, sph, mat = rt.build_dev_scene(20)
@@ -186,7 +191,7 @@ def test_scatter_known_answers(oracle):
     """tests/golden/scatter_kat.json (computed by tests/pyref.py): the oracle's f64 material_scatter, bit for bit"""
     kat = json.load(open(os.path.join(GOLDEN, "scatter_kat.json")))
     fx = lambda v: tuple(float.fromhex(x) for x in v)
-    assert len(kat) >= 60 and {k["type"] for k in kat} == {0, 1, 2, 3, 4, 5} and any(not k["ok"] for k in kat)
+    assert len(kat) >= 60 and {k["type"] for k in kat} == {0, 1, 2, 3, 4, 5, 6} and any(not k["ok"] for k in kat)
     for k in kat:
         material = (k["type"], fx(k["albedo"]), float.fromhex(k["param1"]))
         o_, d_, att, ok = oracle.material_scatter(1, material, fx(k["ray_o"]), fx(k["ray_d"]), fx(k["hit_p"]), fx(k["normal"]), k["front"],
