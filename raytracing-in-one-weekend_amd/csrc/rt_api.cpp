@@ -95,7 +95,7 @@ struct rt_world_s {
     int device = 0;
     int32_t n_spheres = 0, n_padded = 0, n_materials = 0;
     int resident_blocks = 2048;                 // workgroups the device can hold at once
-    uint32_t *queue_ring = nullptr;             // CALL_SLOTS work-queue heads, 64 bytes apart
+    uint32_t *queue_ring = nullptr;             // CALL_SLOTS work-queue heads, 64 bytes apart (a call whose windows overlap uses the word 32 bytes on as well)
     CallSlot slots[CALL_SLOTS];
     uint64_t n_calls = 0;
     int last_slot = -1;
@@ -124,6 +124,11 @@ struct rt_world_s {
     hipEvent_t slabs_done = nullptr;
     hipStream_t slabs_stream = nullptr;
     bool slabs_busy = false;
+    // Ordered mixed mode with more samples than the staging buffer holds: the windows alternate between the halves of the
+    // buffer and between two streams of the world's own, so that a window's first waves fill the compute units its
+    // predecessor's last waves leave idle (a window on its own costs about a millisecond of ramp-up and tail).
+    hipStream_t win_stream[2] = {nullptr, nullptr};
+    hipEvent_t win_fork = nullptr, win_sum[2] = {nullptr, nullptr}, win_join[2] = {nullptr, nullptr};
     void *static_scratch = nullptr;             // this device's copy of the kernels' static scratch array
     std::mutex mu;
 };
@@ -364,6 +369,12 @@ int32_t rt_world_destroy(rt_world *w) {
         if (c.ev_end) (void)hipEventDestroy(c.ev_end);
     }
     if (w->slabs_done) (void)hipEventDestroy(w->slabs_done);
+    for (int k = 0; k < 2; ++k) {
+        if (w->win_stream[k]) { (void)hipStreamSynchronize(w->win_stream[k]); (void)hipStreamDestroy(w->win_stream[k]); }
+        if (w->win_sum[k]) (void)hipEventDestroy(w->win_sum[k]);
+        if (w->win_join[k]) (void)hipEventDestroy(w->win_join[k]);
+    }
+    if (w->win_fork) (void)hipEventDestroy(w->win_fork);
     delete w;
     return RT_OK;
 }
@@ -454,14 +465,16 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
     // scratch beyond the queue head: chunk slabs (literal modes) or staged sample colours (mixed mode)
     size_t work_need = 0;
     int64_t window = sample_count; // mixed mode: samples staged per launch
+    int halves = 1;                // 2: the windows alternate between two halves of the buffer and overlap
     if (mixed) {
         const size_t per_sample = static_cast<size_t>(slab_stride) * sizeof(double);
         const size_t all = per_sample * static_cast<size_t>(std::max<int64_t>(sample_count, 1));
         const size_t cap = src.fixed ? src.work_bytes : std::max(per_sample, std::min(all, std::min(staging_budget(), world->staging_cap)));
         if (cap < per_sample) return fail(RT_ERR_UNSUPPORTED, "one staged sample of this call needs %zu bytes of scratch, %zu are available", per_sample, cap);
         window = std::max<int64_t>(1, std::min<int64_t>(sample_count, static_cast<int64_t>(cap / per_sample)));
+        if (window < sample_count && !src.fixed && cap / 2 >= per_sample) { halves = 2; window = static_cast<int64_t>(cap / 2 / per_sample); }
         if (window < sample_count && window >= unit_samples()) window = window / unit_samples() * unit_samples(); // whole work items
-        work_need = per_sample * static_cast<size_t>(window);
+        work_need = per_sample * static_cast<size_t>(window) * static_cast<size_t>(halves);
     } else if (chunks > 1 && !queue_mode) {
         work_need = static_cast<size_t>(chunks - 1) * static_cast<size_t>(slab_stride) * accum_size(precision);
     }
@@ -479,7 +492,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
                     world->staging_cap = work_need / 2; // later calls start from what fitted
                     window = std::max<int64_t>(1, window / 2);
                     if (window >= unit_samples()) window = window / unit_samples() * unit_samples();
-                    work_need = static_cast<size_t>(slab_stride) * sizeof(double) * static_cast<size_t>(window);
+                    work_need = static_cast<size_t>(slab_stride) * sizeof(double) * static_cast<size_t>(window) * static_cast<size_t>(halves);
                     me = staging_malloc(&world->slabs, work_need);
                 }
                 if (me != hipSuccess) return fail(RT_ERR_DEVICE, "allocating %zu bytes of scratch failed: %s", work_need, hipGetErrorString(me));
@@ -579,7 +592,48 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
         slot->used = true; // from here on something of this call may be in flight
         world->last_slot = slot_index;
     }
-    if (mixed) {
+    if (mixed && halves == 2) {
+        // Overlapping windows.  Window k traces into half k % 2 of the buffer on stream k % 2 and is followed there by its
+        // ordered sum, which first waits for the sum of window k - 1 (the accumulators are added to in sample order).
+        // Window k + 1 starts on the other stream as soon as that stream's previous sum is done, i.e. while window k is
+        // still running: its workgroups take the compute units window k's last waves free.  A half is written again
+        // (window k + 2) only after its sum (window k), in stream order.  The caller's stream forks into the two and
+        // joins them again, so everything the call does lies between the events recorded on it.
+        for (int k = 0; k < 2; ++k) {
+            if (world->win_stream[k] == nullptr) HIP_TRY(hipStreamCreateWithFlags(&world->win_stream[k], hipStreamNonBlocking));
+            if (world->win_sum[k] == nullptr) HIP_TRY(hipEventCreateWithFlags(&world->win_sum[k], hipEventDisableTiming));
+            if (world->win_join[k] == nullptr) HIP_TRY(hipEventCreateWithFlags(&world->win_join[k], hipEventDisableTiming));
+        }
+        if (world->win_fork == nullptr) HIP_TRY(hipEventCreateWithFlags(&world->win_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(world->win_fork, st));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(world->win_stream[k], world->win_fork, 0));
+        const size_t half_elems = static_cast<size_t>(slab_stride) * static_cast<size_t>(window);
+        int k = 0;
+        for (int64_t w0 = 0; w0 < sample_count; w0 += window, ++k) {
+            const int side = k & 1;
+            hipStream_t ws = world->win_stream[side];
+            const int64_t wc = std::min<int64_t>(window, sample_count - w0);
+            const int64_t unit = unit_samples();
+            const int wchunks = static_cast<int>(std::max<int64_t>(1, (wc + unit - 1) / unit));
+            p.sample_begin = static_cast<uint32_t>(sample_begin + w0);
+            p.sample_count = static_cast<uint32_t>(wc);
+            p.chunk_samples = static_cast<uint32_t>(unit);
+            p.n_items = static_cast<uint32_t>(static_cast<int64_t>(wk.map.n_tiles) * wchunks);
+            p.queue = queue + 8 * side;
+            p.slabs = static_cast<double *>(work) + half_elems * static_cast<size_t>(side);
+            r.slabs = p.slabs;
+            r.chunks = static_cast<int32_t>(wc);
+            HIP_TRY(rtk::launch_clear_queue(p.queue, ws));
+            HIP_TRY(rtk::launch_render(p, rtk::ARITH_MIXED, fetch, wchunks, world->resident_blocks, ws));
+            if (k > 0) HIP_TRY(hipStreamWaitEvent(ws, world->win_sum[side ^ 1], 0));
+            HIP_TRY(rtk::launch_order_sum(r, k == 0, ws));
+            HIP_TRY(hipEventRecord(world->win_sum[side], ws));
+        }
+        for (int j = 0; j < 2; ++j) {
+            HIP_TRY(hipEventRecord(world->win_join[j], world->win_stream[j]));
+            HIP_TRY(hipStreamWaitEvent(st, world->win_join[j], 0));
+        }
+    } else if (mixed) {
         // samples in windows of what the staging buffer holds: trace a window (any order), then add its
         // colours to the accumulators in sample order
         for (int64_t w0 = 0; w0 < std::max<int64_t>(sample_count, 1); w0 += window) {

@@ -691,6 +691,10 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 // (plain & and | on the lane predicates: each is a compare into a scalar mask and the combination scalar
                 // logic, where && and || would branch around the second compare)
                 bool ahead;
+#ifdef RT_ENQUEUE_ALL
+                // measurement build: every lane whose line meets the sphere queues it; the evaluation rejects what lies behind
+                if constexpr (WQ) { (void)cc; (void)h; ahead = true; } else
+#endif
                 if constexpr (FILTER) {
                     (void)cc;
                     const float hs = h - s_o, dl = disc - thr_l;

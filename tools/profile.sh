@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py on the GPU box for ONE arithmetic mode; results land in gpurun_out/prof_<mode>/.
-#   usage: tools/profile.sh f32|mixed|f64 [extra bench.py flags]
+#   usage: tools/profile.sh f32|mixed|mixed-fixed|f64 [extra bench.py flags]
 set -u
 export TMPDIR=/tmp
 MODE=${1:-mixed}; shift || true

@@ -57,7 +57,8 @@ if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
 if traffic:
     f, w = traffic.get("traffic_fetch", float("nan")), traffic.get("traffic_write", float("nan"))
     print("== memory-side traffic of one 500-spp dispatch (4.05e8 samples; rocprofv3 reports KiB; FETCH_SIZE doubled as gfx950 tallies 128-B reads at 64 B)")
-    what = "8-byte integer atomics, width uncalibrated" if mode == "f32" else "24-byte stores of the staged sample colours"
+    what = {"f32": "8-byte integer atomics, three per sample, width as counted", "mixed-fixed": "8-byte integer atomics, six per unit of four samples, width as counted",
+            "mixed": "24-byte stores of the staged sample colours"}.get(mode, "")
     print(f"   FETCH_SIZE {f:.6g} KiB -> {2 * f * 1024 / 1e9:.4f} GB read;  WRITE_SIZE {w:.6g} KiB -> {w * 1024 / 1e9:.3f} GB written ({what})")
     allc["TRAFFIC_BYTES_500SPP"] = (2 * f + w) * 1024
 json.dump(allc, open(os.path.join(out, "counters.json"), "w"), indent=1)
