@@ -7,12 +7,14 @@
 //   Throughput mode (QUEUE): work items are (tile, sample chunk) pairs behind one global
 //   counter.  A wave takes an item, deals its units -- (pixel, sample) pairs -- to whichever lanes
 //   are free, and takes the next item when the units run out, while other lanes are still finishing
-//   paths of the previous one.  A finished sample is added to its pixel's Q32.32 accumulator in
-//   HBM with integer atomics, so the sums are exact and independent of which lane, wave or GPU
-//   traced what.  Lanes idle only when the whole queue is empty.
-//   (Fixed-point mixed mode: a unit is one pixel's samples of the chunk; the lane adds their colours
-//   in registers and issues its atomics once per unit -- six 64-bit atomics per sample would exceed
-//   the rate at which the memory side executes them, three do not.)
+//   paths of the previous one.  A finished sample's colour is added in fixed point (Q32.32), so the
+//   sums are exact and independent of which lane, wave or GPU traced what: first to the wave's sums
+//   for the item's tile in LDS, which go to the pixel accumulators in HBM with one set of integer
+//   atomics per pixel and item (an atomic per sample and channel costs 3.5 % of the frame, and six
+//   per sample -- the fixed-point mixed mode's two words per channel -- are more than the memory side
+//   executes).  Lanes idle only when the whole queue is empty.
+//   (Hierarchy variants of the fixed-point mixed mode, whose LDS holds the tree: a unit is one pixel's
+//   samples of the chunk; the lane adds their colours in registers and issues its atomics once per unit.)
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
 //   Mixed mode: f64 paths in the reference's operation order behind the f32 filter scan, whose
@@ -273,7 +275,19 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     __shared__ unsigned long long wq_best[WQ ? WAVES_PER_BLOCK : 1][WQ ? 64 : 1];             // per owner lane: smallest key so far
     __shared__ unsigned long long wq_val[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? WQ_CAP : 1]; // mixed: the entries' roots
     __shared__ uint32_t wq_besti[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? 64 : 1];  // mixed: lowest sphere index among equal roots
+    // Tile sums (queue modes that add fixed-point colours, list scan): the colours of finished samples are added to
+    // per-wave accumulators in LDS -- one set for the tile of the wave's current work item and one for the previous
+    // item's, since its last paths are still in flight -- and a tile's sums go to the accumulators in HBM with one set
+    // of integer atomics per pixel when the wave takes the next item but one.  Integer sums: exact whatever the grouping.
+    // Per sample that is SUM_WORDS LDS atomics and SUM_WORDS / (samples per item) global ones; a sample that outlives two
+    // item changes (a few per cent: paths of ten and more segments) adds to HBM directly.
+    constexpr bool LSUM = QUEUE && BVH == 0 && FETCH == FETCH_SCALAR && (FMA || (MIXED && FIXED));
+    constexpr int SUM_WORDS = (MIXED && FIXED) ? 6 : 3; // 64-bit words per pixel: Q32.32 per channel, or Q32.64 as two words
+    __shared__ unsigned long long tile_sum[LSUM ? WAVES_PER_BLOCK : 1][LSUM ? 2 : 1][LSUM ? 64 * SUM_WORDS : 1];
     const int wave_in_block = threadIdx.x >> 6;
+    if constexpr (LSUM) {
+        for (int k = threadIdx.x & 63; k < 2 * 64 * SUM_WORDS; k += 64) (&tile_sum[wave_in_block][0][0])[k] = 0ull;
+    }
     if constexpr (WQ) {
         wq_best[wave_in_block][threadIdx.x & 63] = ~0ull;
         if constexpr (MIXED) wq_besti[wave_in_block][threadIdx.x & 63] = ~0u;
@@ -335,7 +349,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // the ordered mixed mode 2-5 % (a pixel's paths are alike, so the lanes that drew the long ones fall behind the
     // others and the wave's iterations are worse filled; wave-level dealing runs as often either way), and save the
     // fixed-point mixed mode 7 % (1.5 atomics per sample instead of 6, which is more than the memory side executes).
-    constexpr bool UNITS = MIXED && FIXED;
+    // (Where the tile sums above apply they take the atomics away without that cost; the hierarchy variants, whose LDS
+    // holds the tree, use the units.)
+    constexpr bool UNITS = MIXED && FIXED && !LSUM;
     // queue mode, all wave-uniform: the current item and its units
     uint32_t unit_next = 0, unit_total = 0, npx = 0, item_s_begin = 0, item_s_end = 0;
     int x0 = 0, y0 = 0, tw = TILE, item_tile = 0;
@@ -343,6 +359,35 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // queue mode, per lane: the lane has no unit (and asks for one); one past the last sample of its unit
     bool need_unit = QUEUE;
     uint32_t unit_end = 0;
+    // tile sums: the generation of the wave's current item (it counts the items the wave has taken; wave-uniform), the items
+    // whose sums the two LDS sets hold (~0: none), and per lane (generation << 6 | pixel of the tile) of the sample it traces
+    uint32_t cur_gen = 0, gen_item0 = ~0u, gen_item1 = ~0u, my_slot = 0;
+    // the sums of one set go to HBM and the set is cleared (wave-uniform call)
+    auto flush_tile = [&](const int set, const uint32_t item) {
+        if constexpr (LSUM) {
+            if (item == ~0u) return;
+            const int tile = static_cast<int>(item % static_cast<uint32_t>(P.map.n_tiles));
+            const int fx0 = P.min_x + (tile % P.map.tiles_x) * TILE;
+            const int fy0 = P.min_y + tile_row_of(P.map, tile / P.map.tiles_x) * TILE;
+            const int ftw = min(TILE, P.max_x - fx0);
+            const uint32_t fnpx = static_cast<uint32_t>(ftw * min(TILE, P.max_y - fy0));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t n_here = static_cast<uint32_t>(__builtin_popcountll(here));
+            for (uint32_t q = rank_in(here); q < fnpx; q += n_here) {
+                const int fu = fx0 + static_cast<int>(q % static_cast<uint32_t>(ftw)), fv = fy0 + static_cast<int>(q / static_cast<uint32_t>(ftw));
+                unsigned long long *src = &tile_sum[wave_in_block][set][q * SUM_WORDS];
+                unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + (static_cast<int64_t>(fu) + static_cast<int64_t>(fv) * P.width) * SUM_WORDS;
+#pragma unroll
+                for (int c = 0; c < SUM_WORDS; ++c) {
+                    const unsigned long long w = src[c];
+                    src[c] = 0ull;
+                    if (w != 0ull) atomicAdd(dst + c, w);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else { (void)set; (void)item; }
+    };
     // ordered mixed mode: where this lane's sample colours are stored, (tile * 64 + pixel of the tile) * 3 within a sample's slab
     int64_t stage_px = 0;
     // fixed-point mixed mode: the sum of the unit's sample colours in Q32.64 as {units of 2^-32, units of 2^-64}
@@ -415,7 +460,21 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     uint32_t item = 0u;
                     if (rank_in(__builtin_amdgcn_ballot_w64(true)) == 0u) item = atomicAdd(P.queue, 1u); // one lane per wave
                     item = __builtin_amdgcn_readfirstlane(item);
-                    if (item >= P.n_items) { queue_open = false; break; }
+                    if (item >= P.n_items) {
+                        queue_open = false;
+                        if constexpr (LSUM) {
+                            // no more items: both sets go out now, and what is still in flight adds to HBM directly
+                            flush_tile(0, gen_item0); flush_tile(1, gen_item1);
+                            gen_item0 = ~0u; gen_item1 = ~0u;
+                            cur_gen += 2u;
+                        }
+                        break;
+                    }
+                    if constexpr (LSUM) {
+                        // the new item takes over the set of the item before the previous one, whose sums go out first
+                        ++cur_gen;
+                        if (cur_gen & 1u) { flush_tile(1, gen_item1); gen_item1 = item; } else { flush_tile(0, gen_item0); gen_item0 = item; }
+                    }
                     const uint32_t chunk = item / static_cast<uint32_t>(P.map.n_tiles);
                     const int tile = static_cast<int>(item % static_cast<uint32_t>(P.map.n_tiles));
                     item_tile = tile;
@@ -441,6 +500,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                         s = item_s_begin + si;
                         unit_end = s + 1u;
                     }
+                    if constexpr (LSUM) my_slot = (cur_gen << 6) | q;
                     if (tw == TILE) { u = x0 + static_cast<int>(q & 7u); v = y0 + static_cast<int>(q >> 3); }
                     else { u = x0 + static_cast<int>(q % static_cast<uint32_t>(tw)); v = y0 + static_cast<int>(q / static_cast<uint32_t>(tw)); }
                     pixel = static_cast<uint32_t>(u) + static_cast<uint32_t>(v) * static_cast<uint32_t>(P.width);
@@ -1171,7 +1231,22 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
         }
         if (ended) {
             // pixel_color += sample_color (main.odin:575)
-            if constexpr (MIXED && FIXED) {
+            if constexpr (LSUM) {
+                // fixed-point colour -> the tile's sums in LDS (or HBM directly when the tile's set has gone out already)
+                unsigned long long w[SUM_WORDS];
+                if constexpr (MIXED && FIXED) { to_q32_64(color.x, w[0], w[1]); to_q32_64(color.y, w[2], w[3]); to_q32_64(color.z, w[4], w[5]); }
+                else { w[0] = to_q32_32(color.x); w[1] = to_q32_32(color.y); w[2] = to_q32_32(color.z); }
+                const uint32_t age = cur_gen - (my_slot >> 6);
+                if (age < 2u) {
+                    unsigned long long *dst = &tile_sum[wave_in_block][(my_slot >> 6) & 1u][(my_slot & 63u) * SUM_WORDS];
+#pragma unroll
+                    for (int c = 0; c < SUM_WORDS; ++c) atomicAdd(dst + c, w[c]);
+                } else {
+                    unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * SUM_WORDS;
+#pragma unroll
+                    for (int c = 0; c < SUM_WORDS; ++c) atomicAdd(dst + c, w[c]);
+                }
+            } else if constexpr (MIXED && FIXED) {
                 // Q32.64 in registers: exact integer sums, whatever the order in which lanes, waves or GPUs finish samples
                 const Real ch[3] = {color.x, color.y, color.z};
 #pragma unroll
