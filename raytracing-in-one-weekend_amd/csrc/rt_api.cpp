@@ -204,23 +204,24 @@ int auto_chunks(int32_t n_tiles, int64_t sample_count) {
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(c, 32)));
 }
 
-// Samples per unit of the queue modes (a lane traces that many consecutive samples of one pixel, adds their colours in
-// registers and issues one set of atomics).  RT_MI355X_UNIT_SAMPLES overrides it (a tuning aid).
-int64_t unit_samples() {
-    static const int64_t value = [] {
+// Samples per pixel of a work item of the queue modes: 4 (256 paths per item); 8 for the fixed-point mixed mode, whose
+// tile sums cost six global atomics per pixel and item (measured on the headline frame: 4 -> 8 samples -0.9 %, 16 +0.2 %;
+// the other queue modes are flat from 4 to 8 and lose 1-2 % at 16).  RT_MI355X_UNIT_SAMPLES overrides it (a tuning aid).
+int64_t unit_samples(bool fixed_point_mixed = false) {
+    static const int64_t override_value = [] {
         const char *env = std::getenv("RT_MI355X_UNIT_SAMPLES");
         const long long v = (env != nullptr && env[0] != '\0') ? std::atoll(env) : 0;
-        return static_cast<int64_t>(v >= 1 && v <= 4096 ? v : 4);
+        return static_cast<int64_t>(v >= 1 && v <= 4096 ? v : 0);
     }();
-    return value;
+    return override_value != 0 ? override_value : (fixed_point_mixed ? 8 : 4);
 }
 
-int auto_queue_chunks(int64_t sample_count) {
+int auto_queue_chunks(int64_t sample_count, bool fixed_point_mixed) {
     // work items of a few samples per pixel (some hundred paths): small enough that the items still
     // running when the queue empties are a sliver of the launch, large enough that taking one
     // (an atomic and a few scalar instructions per wave) and flushing a lane's sums (a set of atomics
     // per unit) cost nothing
-    const int64_t unit = unit_samples();
+    const int64_t unit = unit_samples(fixed_point_mixed);
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((sample_count + unit - 1) / unit, 4096)));
 }
 
@@ -450,7 +451,7 @@ int32_t accumulate_impl(rt_world *world, const rt_camera_render_data *cam, int64
                     f64 ? rtk::LDS_MAX_SPHERES_F64 : rtk::LDS_MAX_SPHERES_F32, world->n_spheres);
 
     const bool queue_mode = precision == RT_PRECISION_F32 || mixed || mixed_fixed;
-    int chunks = sample_chunks > 0 && !mixed ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count) : auto_chunks(wk.map.n_tiles, sample_count));
+    int chunks = sample_chunks > 0 && !mixed ? sample_chunks : (queue_mode ? auto_queue_chunks(sample_count, mixed_fixed) : auto_chunks(wk.map.n_tiles, sample_count));
     chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, sample_count))));
     int64_t chunk_samples = sample_count == 0 ? 1 : (sample_count + chunks - 1) / chunks;
     chunks = sample_count == 0 ? 1 : static_cast<int>((sample_count + chunk_samples - 1) / chunk_samples);
