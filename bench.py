@@ -133,10 +133,10 @@ def traffic_model(mode, samples, w, h, n_spheres):
     """memory-side bytes of one frame's kernels, from what they issue (the model the PMC figure is read against)"""
     if mode == "mixed":       # every sample colour staged (24 B written), read once by the ordered sum, accumulators written
         return samples * 24 * 2 + w * h * 24 + n_spheres * 16
-    if mode == "mixed-fixed":  # six 8-byte atomic adds per sample, accumulators cleared once
-        return samples * 6 * 8 + w * h * 48 + n_spheres * 16
-    if mode == "f32":         # three 8-byte atomic adds per sample
-        return samples * 3 * 8 + w * h * 24 + n_spheres * 16
+    if mode == "mixed-fixed":  # tile sums in LDS: six 8-byte atomic adds per pixel and work item (8 samples), accumulators cleared once
+        return samples // 8 * 6 * 8 + w * h * 48 + n_spheres * 16
+    if mode == "f32":         # tile sums in LDS: three 8-byte atomic adds per pixel and work item (4 samples)
+        return samples // 4 * 3 * 8 + w * h * 24 + n_spheres * 16
     return w * h * 24 * 2 + n_spheres * 32   # f64: per-lane register sums, stored once per chunk
 
 
@@ -414,7 +414,8 @@ def main():
                          "traffic_model": traffic_model(args.precision, samples_frame // world_size if args.partition == "samples" else m["samples_rank"], w, h, len(sph)),
                          "algorithmic_bytes": w * h * 24 + len(sph) * 16,
                          "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator atomics or staging stores are a few % of HBM bandwidth. "
-                                         "traffic_model = bytes the kernels of one launch issue (atomics 8 B each, staged colours written and read once)",
+                                         "traffic_model = bytes the kernels of one frame issue (atomics 8 B each -- the counters tally an atomic at 32 B written plus a "
+                                         "read --, staged colours written and read once)",
                          "kernel": KERNEL_TAGS[args.precision], "kernel_ms": m["kernel_s"] * 1e3, "flop_per_test": F_TEST,
                          "executed_flop_per_test": F_TEST_EXECUTED, "frac_executed": m["achieved"] * F_TEST_EXECUTED / F_TEST / PEAK_FP32_TFLOPS,
                          "frac_note": "frac = algorithmic FLOP (17 per ray/sphere test) over peak; the filter scan executes 14 per test, so frac can reach 1.21 and "

@@ -568,7 +568,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(monkeypatch, capsys
     assert set(d["modes"]) == {"f32", "mixed", "mixed-fixed", "f64"} and all(m["value"] > 0 and m["parity"] for m in d["modes"].values())
     assert all(d["modes"][k]["verified"] is True for k in ("f32", "mixed", "mixed-fixed"))
     assert d["roofline"]["traffic_source"] and d["roofline"]["algorithmic_bytes"] > 0
-    assert d["roofline"]["traffic_model"] == 160 * 90 * 8 * 48 + 160 * 90 * 48 + 16 * int(d["config"]["workload"].split("(")[1].split()[0])
+    assert d["roofline"]["traffic_model"] == 160 * 90 * 8 // 8 * 48 + 160 * 90 * 48 + 16 * int(d["config"]["workload"].split("(")[1].split()[0])
     assert d["roofline"]["executed_flop_per_test"] == 14 and abs(d["roofline"]["frac_executed"] * 17 - d["roofline"]["frac"] * 14) < 1e-12
     assert len(d["roofline"]["kernel_source_sha16"]) == 16
     r = d["roofline"]

@@ -31,7 +31,10 @@ for name in ("traffic_fetch", "traffic_write"):
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(f)) if "render_kernel" in row["Kernel_Name"]]
         if vals:
-            traffic[name] = sum(vals) / len(vals)
+            # per FRAME: the pass runs bench.py --steps 1 --warmup 0, which renders two frames (one counted, one timed); a frame
+            # of the ordered mixed mode is several dispatches (one per staging window)
+            traffic[name] = sum(vals) / 2.0
+            traffic[name + "_dispatches_per_frame"] = len(vals) / 2.0
 print("== PMC means per render_kernel dispatch (bench.py --steps 1 --warmup 0 --spp 100: 8.1e7 samples per dispatch)")
 for c in sorted(allc):
     print(f"   {c:28s} {allc[c]:.6g}")
@@ -56,8 +59,9 @@ if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
         print(f"   wave time              : issue-stalled {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}, parked on waitcnt {g('SQ_WAIT_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}, executing {g('SQ_ACTIVE_INST_ANY', 0) / g('SQ_WAVE_CYCLES'):.3f}")
 if traffic:
     f, w = traffic.get("traffic_fetch", float("nan")), traffic.get("traffic_write", float("nan"))
-    print("== memory-side traffic of one 500-spp dispatch (4.05e8 samples; rocprofv3 reports KiB; FETCH_SIZE doubled as gfx950 tallies 128-B reads at 64 B)")
-    what = {"f32": "8-byte integer atomics, three per sample, width as counted", "mixed-fixed": "8-byte integer atomics, six per unit of four samples, width as counted",
+    print(f"== memory-side traffic of the render kernel over one 500-spp frame (4.05e8 samples, {traffic.get('traffic_write_dispatches_per_frame', 1):.0f} dispatch(es); rocprofv3 reports KiB; FETCH_SIZE doubled as gfx950 tallies 128-B reads at 64 B)")
+    what = {"f32": "8-byte integer atomics, three per pixel and work item of 4 samples (tile sums in LDS), width as counted",
+            "mixed-fixed": "8-byte integer atomics, six per pixel and work item of 8 samples (tile sums in LDS), width as counted",
             "mixed": "24-byte stores of the staged sample colours"}.get(mode, "")
     print(f"   FETCH_SIZE {f:.6g} KiB -> {2 * f * 1024 / 1e9:.4f} GB read;  WRITE_SIZE {w:.6g} KiB -> {w * 1024 / 1e9:.3f} GB written ({what})")
     allc["TRAFFIC_BYTES_500SPP"] = (2 * f + w) * 1024
