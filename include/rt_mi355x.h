@@ -133,7 +133,8 @@ typedef struct { int64_t min_x, min_y, one_past_max_x, one_past_max_y; } rt_rect
 #define RT_FETCH_LDS 2    /* list scan, SoA records staged once per workgroup into LDS, broadcast  */
 #define RT_FETCH_BVH 3    /* bounding-volume hierarchy over the spheres instead of the list (the
                              TODO at main.odin:559); RT_PRECISION_F32 and RT_PRECISION_MIXED; the image is
-                             the list scan's bit for bit (with RT_PRECISION_MIXED: the f64 image),
+                             the list scan's bit for bit (with RT_PRECISION_MIXED: the f64 image; also
+                             RT_PRECISION_MIXED_FIXED),
                              RT_STAT_SPHERE_TESTS counts the tests carried out.
                              A hierarchy of at most 1280 nodes (about 640 spheres) is staged into LDS  */
 #define RT_FETCH_BVH_GLOBAL 4 /* the same with the hierarchy read from global memory whatever its size
@@ -245,8 +246,16 @@ int32_t rt_world_destroy(rt_world *world);
  * with the SUM of its samples' colours.  Element type by precision:
  *   RT_PRECISION_MIXED       double, summed in sample order whatever sample_chunks
  *                            says (the colours of up to RT_MI355X_STAGING_MIB -- default
- *                            12288 -- MiB worth of samples, 24 bytes each, are staged in a
- *                            buffer the world owns and added by a second kernel);
+ *                            4096 -- MiB worth of samples, 24 bytes each, are staged in a
+ *                            buffer the world owns and added by a second kernel; more samples
+ *                            pass through it in windows that overlap on two streams of the
+ *                            world's own, which the caller's stream waits for; an allocation
+ *                            the device refuses is retried at half the size);
+ *   RT_PRECISION_MIXED_FIXED two uint64_t {a, b} per element (16 bytes): the exact sum of the
+ *                            colours, each truncated to a multiple of 2^-64, as a * 2^-32 +
+ *                            b * 2^-64.  Only that value is defined, not the split between the
+ *                            words; element-wise integer addition of two such buffers (a split
+ *                            of the samples over calls or GPUs) adds the values;
  *   RT_PRECISION_F32         uint64_t, Q32.32 fixed point (each f32 sample colour is
  *                            truncated to 2^-32 and added exactly, so sums over any
  *                            split of the samples -- chunks, calls, GPUs -- are equal);
@@ -319,10 +328,14 @@ int64_t rt_world_last_kernel_ns(rt_world *world);
  * RT_ERR_UNSUPPORTED otherwise (pass a smaller sample_chunks -- 1 needs no
  * slabs -- or fewer pixels per call), and for RT_FETCH_BVH unless an earlier
  * rt_render_accumulate on this world has built the hierarchy.
- * RT_PRECISION_F32 needs only the queue head and is never refused for size.
+ * RT_PRECISION_F32 and RT_PRECISION_MIXED_FIXED need only the queue head and are
+ * never refused for size.
  * Every call on a GPU shares that GPU's array: calls that overlap in time on
  * one GPU race on it (whatever world or stream they use); calls issued one
- * after the other on one stream do not.
+ * after the other on one stream do not.  While `stream` is being captured into
+ * a HIP graph the call records no events and does not synchronise with the
+ * host; rt_world_last_kernel_ns then keeps referring to the last call made
+ * outside a capture.
  */
 int32_t rt_render_accumulate_static(rt_world *world, const rt_camera_render_data *cam,
                                     int64_t width, int64_t height, rt_rect region,
