@@ -779,6 +779,7 @@ struct DeviceCache {
 };
 DeviceCache g_cache[MAX_DEVICES];
 constexpr size_t PINNED_STAGING_MAX = static_cast<size_t>(1) << 30; // larger results are copied straight into the caller's memory
+constexpr size_t ONE_SHOT_STAGING_KEPT = static_cast<size_t>(256) << 20; // a cached world's staging buffer above this is freed when the call returns
 
 hipError_t ensure_bytes(void **buf, size_t *have, size_t need) {
     if (*buf != nullptr && *have >= need) return hipSuccess;
@@ -853,7 +854,18 @@ int32_t render_to_host(rt_v3 *image_data, char *ppm_body, int64_t width, int64_t
         for (auto &d : devs) {
             (void)hipSetDevice(d.device);
             if (d.stream) (void)hipStreamSynchronize(d.stream);
-            if (d.cached) continue; // kept for the next call
+            if (d.cached) {
+                // kept for the next call -- except a large staging buffer of the ordered mixed mode: a host that calls once
+                // per frame should not hold gigabytes between frames (allocating it again costs a few ms of a frame that
+                // takes a hundred; the small buffers of a benchmark loop over a small image stay)
+                rt_world *w = d.world;
+                if (w != nullptr && w->slabs != nullptr && w->slab_bytes > ONE_SHOT_STAGING_KEPT) {
+                    std::lock_guard<std::mutex> wl(w->mu);
+                    (void)hipFree(w->slabs);
+                    w->slabs = nullptr; w->slab_bytes = 0; w->slabs_busy = false;
+                }
+                continue;
+            }
             if (d.stream) (void)hipStreamDestroy(d.stream);
             if (d.accum) (void)hipFree(d.accum);
             if (d.image) (void)hipFree(d.image);

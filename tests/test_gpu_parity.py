@@ -1074,3 +1074,23 @@ def test_staging_allocation_falls_back_to_a_smaller_window(rt, oracle, monkeypat
         image, linear, stats = gpu_render(rt, cs, cam, sph, mat, seed=2, precision=rt.PRECISION_MIXED)
         assert np.array_equal(image, ref["image"]) and int(stats[0]) == int(ref["stats"][0])
     rt.release_cache()
+
+
+def test_one_shot_calls_do_not_hold_a_large_staging_buffer(rt):
+    """rt_render_region in the default (ordered mixed) mode stages 24 bytes per pixel and sample while it runs; a buffer of
+    more than 256 MiB is given back when the call returns, the rest of what the call cached (world, accumulators, image) stays"""
+    import torch
+    cs, cam, sph, mat = scene(rt, "final", 1200, 20)        # 389 MB of staged colours
+    w, h = cs.image_width, cs.image_height
+    rt.release_cache()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    image = np.zeros((h, w, 3))
+    rt.render_region(image, (0, 0, w, h), cam, sph, mat, seed=2)
+    torch.cuda.synchronize()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert 0 <= held < (128 << 20), held                     # world + f64 accumulators + image of a 1200x675 frame: 40 MB
+    again = np.zeros((h, w, 3))
+    rt.render_region(again, (0, 0, w, h), cam, sph, mat, seed=2)   # allocates the buffer again: same image
+    assert np.array_equal(again, image) and image.min() >= 0 and image.max() > 0.5
+    rt.release_cache()
