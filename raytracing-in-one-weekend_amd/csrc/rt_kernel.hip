@@ -163,6 +163,101 @@ template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> random_u
     return scale_down<Real, FAST>(p, sqrt_rn(lsq));
 }
 
+// number of lanes below this one whose bit is set in `mask`
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// The rejection loop of random_unit_vector run by the WAVE (main.odin:196-202; same candidates, same result).  Alone, a
+// lane tries its stream's candidates one after the other -- 52 % are accepted -- and the wave repeats the loop body until
+// its unluckiest lane is through: five trips where the mean lane needs 1.9.  Here every lane that needs a vector tries its
+// candidate 0; then the lanes still searching (the owners) have their next candidates tried by ALL 64 lanes at once, 1 to
+// 16 candidates per owner depending on how many owners are left; an owner takes the lowest-numbered accepted one, which
+// is the one its own loop would have stopped at.  Two rounds in nearly every case.  What travels is the candidate's three
+// 24-bit draws; the owner forms the vector from them exactly as its own loop would.
+// `first_unit_candidate` must be called by all lanes of the wave that are still running, in converged control flow.
+__device__ __forceinline__ uint32_t stream_draw24(uint32_t kb, uint32_t wp, uint32_t n) { return (mix32(kb + 0xc2b2ae35u * n) ^ wp) >> 8; } // draw n = 1, 2, ...
+template <typename Real> __device__ __forceinline__ bool unit_candidate_accepted(uint32_t kx, uint32_t ky, uint32_t kz) {
+    if constexpr (std::is_same<Real, double>::value) {
+        // the integer form of random_unit_vector_f64: |p|^2 = (X^2 + Y^2 + Z^2) * 2^-46, exact
+        const double X = static_cast<double>(static_cast<int32_t>(kx) - 8388608), Y = static_cast<double>(static_cast<int32_t>(ky) - 8388608),
+                     Z = static_cast<double>(static_cast<int32_t>(kz) - 8388608);
+        const double sq = __builtin_fma(Z, Z, __builtin_fma(Y, Y, X * X));
+        return 0.0 < sq && sq <= 70368744177664.0;
+    } else {
+        const V3<float> p = {fma_rn(static_cast<float>(kx), 1.0f / 8388608.0f, -1.0f), fma_rn(static_cast<float>(ky), 1.0f / 8388608.0f, -1.0f),
+                             fma_rn(static_cast<float>(kz), 1.0f / 8388608.0f, -1.0f)};
+        const float lsq = dot(p, p);
+        return 0.0f < lsq && lsq <= 1.0f;
+    }
+}
+template <typename Real>
+__device__ __forceinline__ void first_unit_candidate(const bool need, const uint32_t kb, const uint32_t wp, uint32_t *slot, const int lane,
+                                                     uint32_t &kx, uint32_t &ky, uint32_t &kz) {
+    bool done = !need;
+    if (need) {
+        kx = stream_draw24(kb, wp, 1u); ky = stream_draw24(kb, wp, 2u); kz = stream_draw24(kb, wp, 3u);
+        done = unit_candidate_accepted<Real>(kx, ky, kz);
+    }
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(!done);
+    if (pending == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64(true) != ~0ull) {
+        // some lanes of the wave have left already (the end of a launch): every lane for itself
+        if (!done) {
+            for (uint32_t c = 1u; c < static_cast<uint32_t>(REJECTION_CAP); ++c) {
+                kx = stream_draw24(kb, wp, 3u * c + 1u); ky = stream_draw24(kb, wp, 3u * c + 2u); kz = stream_draw24(kb, wp, 3u * c + 3u);
+                if (unit_candidate_accepted<Real>(kx, ky, kz)) break;
+            }
+        }
+        return;
+    }
+    uint32_t base = 1u; // candidates tried so far per owner
+    while (pending != 0ull) {
+        const uint32_t owners = static_cast<uint32_t>(__builtin_popcountll(pending));
+        const uint32_t shift = owners <= 4u ? 4u : (owners <= 8u ? 3u : (owners <= 16u ? 2u : (owners <= 32u ? 1u : 0u))); // 2^shift candidates per owner
+        const uint32_t my_rank = rank_in(pending);
+        if (!done) slot[my_rank] = static_cast<uint32_t>(lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t oi = static_cast<uint32_t>(lane) >> shift, c = static_cast<uint32_t>(lane) & ((1u << shift) - 1u);
+        const bool helping = oi < owners;
+        const int owner = helping ? static_cast<int>(slot[oi]) : lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t okb = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(owner << 2, static_cast<int>(kb)));
+        const uint32_t owp = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(owner << 2, static_cast<int>(wp)));
+        // the loop ends after REJECTION_CAP candidates with the last one, accepted or not
+        const uint32_t cand = min(base + c, static_cast<uint32_t>(REJECTION_CAP) - 1u);
+        const uint32_t hx = stream_draw24(okb, owp, 3u * cand + 1u), hy = stream_draw24(okb, owp, 3u * cand + 2u), hz = stream_draw24(okb, owp, 3u * cand + 3u);
+        const bool ok = helping && (unit_candidate_accepted<Real>(hx, hy, hz) || cand == static_cast<uint32_t>(REJECTION_CAP) - 1u);
+        const unsigned long long accepted = __builtin_amdgcn_ballot_w64(ok);
+        // an owner's helpers are the lanes [rank << shift, (rank + 1) << shift): the lowest accepted candidate wins
+        const unsigned long long mine = (accepted >> (my_rank << shift)) & ((1ull << (1u << shift)) - 1ull);
+        const bool found = !done && mine != 0ull;
+        const int src = found ? static_cast<int>((my_rank << shift) + static_cast<uint32_t>(__builtin_ctzll(mine))) : lane;
+        const uint32_t fx = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src << 2, static_cast<int>(hx)));
+        const uint32_t fy = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src << 2, static_cast<int>(hy)));
+        const uint32_t fz = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src << 2, static_cast<int>(hz)));
+        if (found) { kx = fx; ky = fy; kz = fz; done = true; }
+        pending = __builtin_amdgcn_ballot_w64(!done);
+        base += 1u << shift;
+    }
+}
+// the unit vector of an accepted candidate, as the loops of random_unit_vector / random_unit_vector_f64 form it
+template <typename Real, bool FAST> __device__ __forceinline__ V3<Real> unit_vector_of_candidate(uint32_t kx, uint32_t ky, uint32_t kz) {
+    if constexpr (std::is_same<Real, double>::value) {
+        const double X = static_cast<double>(static_cast<int32_t>(kx) - 8388608), Y = static_cast<double>(static_cast<int32_t>(ky) - 8388608),
+                     Z = static_cast<double>(static_cast<int32_t>(kz) - 8388608);
+        const double sq = __builtin_fma(Z, Z, __builtin_fma(Y, Y, X * X));
+        const double scale = 1.0 / 8388608.0;
+        const V3<double> p = {X * scale, Y * scale, Z * scale};
+        const double len = sqrt_rn(sq * (1.0 / 70368744177664.0));
+        return {p.x / len, p.y / len, p.z / len};
+    } else {
+        const V3<float> p = {fma_rn(static_cast<float>(kx), 1.0f / 8388608.0f, -1.0f), fma_rn(static_cast<float>(ky), 1.0f / 8388608.0f, -1.0f),
+                             fma_rn(static_cast<float>(kz), 1.0f / 8388608.0f, -1.0f)};
+        return scale_down<float, FAST>(p, sqrt_rn(dot(p, p)));
+    }
+}
+
 // ----------------------------------------------------------------------------- optics
 // reflect (main.odin:77-80)
 template <typename Real> __device__ __forceinline__ V3<Real> reflect(V3<Real> v, V3<Real> n) { return v - (Real(2) * dot(v, n)) * n; }
@@ -227,10 +322,6 @@ typedef float F2 __attribute__((ext_vector_type(2)));
 struct Pair { F2 cx, cy, cz, k; }; // two spheres' scan records, component-wise
 __device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); } // v_pk_fma_f32
 
-// number of lanes below this one whose bit is set in `mask`
-__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-}
 
 #ifndef RT_WAVES_PER_EU
 // The mixed kernel is compiled for four waves per SIMD: squeezed into the 96 registers of five it spills 45 of them
@@ -284,6 +375,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     constexpr bool LSUM = QUEUE && BVH == 0 && FETCH == FETCH_SCALAR && (FMA || (MIXED && FIXED));
     constexpr int SUM_WORDS = (MIXED && FIXED) ? 6 : 3; // 64-bit words per pixel: Q32.32 per channel, or Q32.64 as two words
     __shared__ unsigned long long tile_sum[LSUM ? WAVES_PER_BLOCK : 1][LSUM ? 2 : 1][LSUM ? 64 * SUM_WORDS : 1];
+    // queue modes: the wave runs random_unit_vector's rejection loop together (first_unit_candidate); 64 words of LDS per wave
+    constexpr bool COOP = QUEUE;
+    __shared__ uint32_t coop_slot[COOP ? (BVH == 2 ? BVH_LDS_BLOCK_THREADS / 64 : WAVES_PER_BLOCK) : 1][COOP ? 64 : 1];
     const int wave_in_block = threadIdx.x >> 6;
     if constexpr (LSUM) {
         for (int k = threadIdx.x & 63; k < 2 * 64 * SUM_WORDS; k += 64) (&tile_sum[wave_in_block][0][0])[k] = 0ull;
@@ -1118,6 +1212,15 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             if (!is_hit || mtype != 0) unit = normalize<Real, FMA>((is_hit && mtype != 2) ? reflect(rd, nrm) : rd);
         }
         auto normalized = [&](const V3<Real> x) -> V3<Real> { if constexpr (SHARED_NORMALIZE) { (void)x; return unit; } else return normalize<Real, FMA>(x); };
+        // random_unit_vector for the lanes that hit a lambertian or a metal (main.odin:299, :321), by the wave together
+        uint32_t cand_x = 0u, cand_y = 0u, cand_z = 0u;
+        if constexpr (COOP) {
+            const bool need = is_hit && mtype != 2;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                const uint32_t kb_scatter = mix32(ks ^ (0x85ebca6bu * (static_cast<uint32_t>(bounce) + 2u))); // the stream of (pixel, sample, bounce + 1)
+                first_unit_candidate<Real>(need, kb_scatter, wp, coop_slot[wave_in_block], lane, cand_x, cand_y, cand_z);
+            }
+        }
         if (is_hit) {
             Draws g(ks, wp, static_cast<uint32_t>(bounce) + 1u);
             V3<Real> dir;
@@ -1147,7 +1250,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 dir = do_reflect ? reflect(unit_d, nrm) : refract(unit_d, nrm, rel);
                 atten = {Real(1), Real(1), Real(1)};
             } else {
-                const V3<Real> ruv = random_unit_vector<Real, FMA>(g);
+                V3<Real> ruv;
+                if constexpr (COOP) ruv = unit_vector_of_candidate<Real, FMA>(cand_x, cand_y, cand_z);
+                else ruv = random_unit_vector<Real, FMA>(g);
                 if (mtype == 0) {
                     // lambertian_proc (main.odin:292-312)
                     dir = nrm + ruv;
