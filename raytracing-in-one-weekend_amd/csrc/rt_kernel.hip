@@ -21,6 +21,8 @@
 //   error margin never drops a sphere the f64 test would hit (the bound is derived at the scan).  Lanes pool work as in throughput mode; every sample's colour is
 //   stored to its own slot and a second kernel adds the slots in sample order, so the image is the
 //   f64 literal mode's bit for bit.
+//   Shading follows the reference line by line; the one loop in it that a wave would repeat until its unluckiest lane
+//   is through -- the rejection sampling of random_unit_vector -- is run by the wave together (first_unit_candidate).
 // Closest-hit scan (throughput and mixed mode)
 //   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, -K0,-K1},
 //   K = |c|^2 - r^2 lowered by an error margin, come through the scalar cache into SGPRs, the next group
