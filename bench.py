@@ -113,9 +113,10 @@ def kernel_source_hash():
 def measured_traffic(args):
     """HBM-side bytes of one render launch of the default workload from the committed rocprofv3 FETCH_SIZE /
     WRITE_SIZE passes over this same command (tools/profile.sh); not measured in this run.  Returns (bytes,
-    source): the source says `stale` when the kernels have changed since the passes were taken."""
+    source, counters): the source says `stale` when the kernels have changed since the passes were taken;
+    counters = what the spec asks to be reported from rocprof beside the roofline (VALU busy, lane utilisation)."""
     if (args.scene, args.width, args.spp, args.gpus) != ("final", 1200, 500, 1) or args.fetch.startswith("bvh"):
-        return None, "none: the committed rocprofv3 passes cover the default single-GPU workload only"
+        return None, "none: the committed rocprofv3 passes cover the default single-GPU workload only", None
     for name in PMC_SUMMARIES:
         try:
             with open(os.path.join(ROOT, name)) as f:
@@ -125,8 +126,14 @@ def measured_traffic(args):
             continue
         recorded = d.get("kernel_source_sha16")
         state = "current" if recorded == kernel_source_hash() else ("stale" if recorded else "stale (taken before source hashes were recorded)")
-        return value, f"{name}, {state}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not measured in this run"
-    return None, "none: no committed rocprofv3 pass covers this precision"
+        c, derived = d.get(args.precision, {}), None
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU"):
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
+            derived = {"valu_busy_pct": 100.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / cycles,   # per SIMD, 1024 SIMDs
+                       "valu_lane_utilization": c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_INSTS_VALU"]),
+                       "source": f"{name}, {state}: rocprofv3 --pmc SQ_* passes at 100 spp (tools/profile.sh)"}
+        return value, f"{name}, {state}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not measured in this run", derived
+    return None, "none: no committed rocprofv3 pass covers this precision", None
 
 
 def traffic_model(mode, samples, w, h, n_spheres):
@@ -395,7 +402,7 @@ def main():
         if world_size > 1:
             partition = (f"8-row strips dealt over the ranks, gather of each rank's rows to rank 0 ({backend})" if args.partition == "rows"
                          else f"sample split, all-reduce of the fixed-point accumulators ({backend})")
-        traffic, traffic_source = measured_traffic(args)
+        traffic, traffic_source, rocprof_counters = measured_traffic(args)
         out = {
             "metric": "Msamples/sec (whole node), final scene 1200x675 500spp; % FP32 VALU peak" if (args.scene, w, total_spp) == ("final", 1200, 500)
                       else f"Msamples/sec (whole node), {args.scene} scene {w}x{h} {total_spp}spp; % FP32 VALU peak",
@@ -410,7 +417,7 @@ def main():
             "segments_per_sample": m["segments"] / max(1, m["samples_rank"]),
             "lane_utilization": m["segments"] / max(1, 64 * m["wave_iters"]),
             "roofline": {"bound": "valu_fp32", "achieved": m["achieved"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": m["achieved"] / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic": traffic, "traffic_source": traffic_source, "rocprof": rocprof_counters,
                          "traffic_model": traffic_model(args.precision, samples_frame // world_size if args.partition == "samples" else m["samples_rank"], w, h, len(sph)),
                          "algorithmic_bytes": w * h * 24 + len(sph) * 16,
                          "traffic_note": "not the bound: the kernel is VALU-bound; the accumulator atomics or staging stores are a few % of HBM bandwidth. "
