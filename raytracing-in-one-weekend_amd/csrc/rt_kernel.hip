@@ -368,21 +368,29 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     __shared__ unsigned long long wq_best[WQ ? WAVES_PER_BLOCK : 1][WQ ? 64 : 1];             // per owner lane: smallest key so far
     __shared__ unsigned long long wq_val[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? WQ_CAP : 1]; // mixed: the entries' roots
     __shared__ uint32_t wq_besti[(WQ && MIXED) ? WAVES_PER_BLOCK : 1][(WQ && MIXED) ? 64 : 1];  // mixed: lowest sphere index among equal roots
-    // Tile sums (queue modes that add fixed-point colours, list scan): the colours of finished samples are added to
+    // Tile sums (queue modes that add fixed-point colours): the colours of finished samples are added to
     // per-wave accumulators in LDS -- one set for the tile of the wave's current work item and one for the previous
     // item's, since its last paths are still in flight -- and a tile's sums go to the accumulators in HBM with one set
     // of integer atomics per pixel when the wave takes the next item but one.  Integer sums: exact whatever the grouping.
     // Per sample that is SUM_WORDS LDS atomics and SUM_WORDS / (samples per item) global ones; a sample that outlives two
     // item changes (a few per cent: paths of ten and more segments) adds to HBM directly.
-    constexpr bool LSUM = QUEUE && BVH == 0 && FETCH == FETCH_SCALAR && (FMA || (MIXED && FIXED));
+    // Hierarchy variants: where the tree is staged into LDS (BVH == 2) there is room for the current item's set only (its
+    // stragglers add to HBM directly: about a third of the samples, 2.5 atomics per sample and channel pair in all); the f32
+    // kernel, which runs six waves per SIMD there, keeps its per-sample atomics instead of giving two of them up for the sums.
+    constexpr bool LSUM = QUEUE && FETCH == FETCH_SCALAR && ((FMA && BVH != 2) || (MIXED && FIXED));
+    static_assert(!(MIXED && FIXED) || LSUM, "the fixed-point mixed mode adds its colours through the tile sums");
+    constexpr int GENS = BVH == 2 ? 1 : 2; // sets of sums: items of the wave that are current at a time
     constexpr int SUM_WORDS = (MIXED && FIXED) ? 6 : 3; // 64-bit words per pixel: Q32.32 per channel, or Q32.64 as two words
-    __shared__ unsigned long long tile_sum[LSUM ? WAVES_PER_BLOCK : 1][LSUM ? 2 : 1][LSUM ? 64 * SUM_WORDS : 1];
+    __shared__ unsigned long long tile_sum[LSUM ? (BVH == 2 ? BVH_LDS_BLOCK_THREADS / 64 : WAVES_PER_BLOCK) : 1][LSUM ? GENS : 1][LSUM ? 64 * SUM_WORDS : 1];
     // queue modes: the wave runs random_unit_vector's rejection loop together (first_unit_candidate); 64 words of LDS per wave
-    constexpr bool COOP = QUEUE;
-    __shared__ uint32_t coop_slot[COOP ? (BVH == 2 ? BVH_LDS_BLOCK_THREADS / 64 : WAVES_PER_BLOCK) : 1][COOP ? 64 : 1];
+    // (kernels with the wave candidate queue lend it the queue's entries, which are free while a segment is shaded).
+    // List scan only: in the hierarchy variants, which live on occupancy, its registers cost more than it saves (measured
+    // same-box: f32 from LDS 33.0 -> 39.8 ms as the kernel drops from six waves per SIMD to four, mixed +2 %).
+    constexpr bool COOP = QUEUE && BVH == 0;
+    __shared__ uint32_t coop_slot[(COOP && !WQ) ? (BVH == 2 ? BVH_LDS_BLOCK_THREADS / 64 : WAVES_PER_BLOCK) : 1][(COOP && !WQ) ? 64 : 1];
     const int wave_in_block = threadIdx.x >> 6;
     if constexpr (LSUM) {
-        for (int k = threadIdx.x & 63; k < 2 * 64 * SUM_WORDS; k += 64) (&tile_sum[wave_in_block][0][0])[k] = 0ull;
+        for (int k = threadIdx.x & 63; k < GENS * 64 * SUM_WORDS; k += 64) (&tile_sum[wave_in_block][0][0])[k] = 0ull;
     }
     if constexpr (WQ) {
         wq_best[wave_in_block][threadIdx.x & 63] = ~0ull;
@@ -440,21 +448,16 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     // literal modes: one tile and one sample chunk per wave
     uint32_t s_end = 0;
     bool inside = false;
-    // A unit of work in queue mode: one (pixel, sample) pair; with UNITS one pixel's samples of the item's chunk, whose
-    // colours the lane adds up in registers.  Measured on the headline frame: per-pixel units cost the throughput and
-    // the ordered mixed mode 2-5 % (a pixel's paths are alike, so the lanes that drew the long ones fall behind the
-    // others and the wave's iterations are worse filled; wave-level dealing runs as often either way), and save the
-    // fixed-point mixed mode 7 % (1.5 atomics per sample instead of 6, which is more than the memory side executes).
-    // (Where the tile sums above apply they take the atomics away without that cost; the hierarchy variants, whose LDS
-    // holds the tree, use the units.)
-    constexpr bool UNITS = MIXED && FIXED && !LSUM;
+    // A unit of work in queue mode: one (pixel, sample) pair.  (Measured on the headline frame: units of one pixel's whole
+    // sample chunk, summed in registers, cost 2-5 % where the atomics are not the bound: a pixel's paths are alike, so
+    // the lanes that drew the long ones fall behind the others and the wave's iterations are worse filled.  The tile
+    // sums above take the atomics away without that cost.)
     // queue mode, all wave-uniform: the current item and its units
     uint32_t unit_next = 0, unit_total = 0, npx = 0, item_s_begin = 0, item_s_end = 0;
     int x0 = 0, y0 = 0, tw = TILE, item_tile = 0;
     bool queue_open = true;
-    // queue mode, per lane: the lane has no unit (and asks for one); one past the last sample of its unit
+    // queue mode, per lane: the lane has no unit (and asks for one)
     bool need_unit = QUEUE;
-    uint32_t unit_end = 0;
     // tile sums: the generation of the wave's current item (it counts the items the wave has taken; wave-uniform), the items
     // whose sums the two LDS sets hold (~0: none), and per lane (generation << 6 | pixel of the tile) of the sample it traces
     uint32_t cur_gen = 0, gen_item0 = ~0u, gen_item1 = ~0u, my_slot = 0;
@@ -486,9 +489,6 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
     };
     // ordered mixed mode: where this lane's sample colours are stored, (tile * 64 + pixel of the tile) * 3 within a sample's slab
     int64_t stage_px = 0;
-    // fixed-point mixed mode: the sum of the unit's sample colours in Q32.64 as {units of 2^-32, units of 2^-64}
-    unsigned long long sum_q[3] = {0ull, 0ull, 0ull};
-    uint32_t sum_lo[3] = {0u, 0u, 0u};
 
     if constexpr (!QUEUE) {
         const int tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -560,16 +560,18 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                         queue_open = false;
                         if constexpr (LSUM) {
                             // no more items: both sets go out now, and what is still in flight adds to HBM directly
-                            flush_tile(0, gen_item0); flush_tile(1, gen_item1);
+                            flush_tile(0, gen_item0);
+                            if constexpr (GENS == 2) flush_tile(1, gen_item1);
                             gen_item0 = ~0u; gen_item1 = ~0u;
-                            cur_gen += 2u;
+                            cur_gen += static_cast<uint32_t>(GENS);
                         }
                         break;
                     }
                     if constexpr (LSUM) {
-                        // the new item takes over the set of the item before the previous one, whose sums go out first
+                        // the new item takes over the set of the item before the previous one (with one set: of the previous
+                        // one), whose sums go out first
                         ++cur_gen;
-                        if (cur_gen & 1u) { flush_tile(1, gen_item1); gen_item1 = item; } else { flush_tile(0, gen_item0); gen_item0 = item; }
+                        if (GENS == 2 && (cur_gen & 1u)) { flush_tile(1, gen_item1); gen_item1 = item; } else { flush_tile(0, gen_item0); gen_item0 = item; }
                     }
                     const uint32_t chunk = item / static_cast<uint32_t>(P.map.n_tiles);
                     const int tile = static_cast<int>(item % static_cast<uint32_t>(P.map.n_tiles));
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                     item_s_begin = min(P.sample_count, chunk * P.chunk_samples);
                     item_s_end = min(P.sample_count, item_s_begin + P.chunk_samples);
                     npx = static_cast<uint32_t>(tw * min(TILE, P.max_y - y0)); // pixels of the tile inside the region
-                    unit_total = UNITS ? (item_s_end > item_s_begin ? npx : 0u) : npx * (item_s_end - item_s_begin);
+                    unit_total = npx * (item_s_end - item_s_begin);
                     unit_next = 0u;
                     continue;
                 }
@@ -589,13 +591,9 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 if (take) {
                     const uint32_t index = unit_next + rank_in(pending);
                     uint32_t q; // pixel within the tile
-                    if constexpr (UNITS) { q = index; s = item_s_begin; unit_end = item_s_end; }
-                    else {
-                        uint32_t si; // sample within the item
-                        if (npx == 64u) { q = index & 63u; si = index >> 6; } else { q = index % npx; si = index / npx; }
-                        s = item_s_begin + si;
-                        unit_end = s + 1u;
-                    }
+                    uint32_t si; // sample within the item
+                    if (npx == 64u) { q = index & 63u; si = index >> 6; } else { q = index % npx; si = index / npx; }
+                    s = item_s_begin + si;
                     if constexpr (LSUM) my_slot = (cur_gen << 6) | q;
                     if (tw == TILE) { u = x0 + static_cast<int>(q & 7u); v = y0 + static_cast<int>(q >> 3); }
                     else { u = x0 + static_cast<int>(q % static_cast<uint32_t>(tw)); v = y0 + static_cast<int>(q / static_cast<uint32_t>(tw)); }
@@ -1225,7 +1223,7 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
             const bool need = is_hit && mtype != 2;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
                 const uint32_t kb_scatter = mix32(ks ^ (0x85ebca6bu * (static_cast<uint32_t>(bounce) + 2u))); // the stream of (pixel, sample, bounce + 1)
-                first_unit_candidate<Real>(need, kb_scatter, wp, coop_slot[wave_in_block], lane, cand_x, cand_y, cand_z);
+                first_unit_candidate<Real>(need, kb_scatter, wp, WQ ? wq_entry[wave_in_block] : coop_slot[wave_in_block], lane, cand_x, cand_y, cand_z);
             }
         }
         if (is_hit) {
@@ -1349,25 +1347,14 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 if constexpr (MIXED && FIXED) { to_q32_64(color.x, w[0], w[1]); to_q32_64(color.y, w[2], w[3]); to_q32_64(color.z, w[4], w[5]); }
                 else { w[0] = to_q32_32(color.x); w[1] = to_q32_32(color.y); w[2] = to_q32_32(color.z); }
                 const uint32_t age = cur_gen - (my_slot >> 6);
-                if (age < 2u) {
-                    unsigned long long *dst = &tile_sum[wave_in_block][(my_slot >> 6) & 1u][(my_slot & 63u) * SUM_WORDS];
+                if (age < static_cast<uint32_t>(GENS)) {
+                    unsigned long long *dst = &tile_sum[wave_in_block][GENS == 2 ? ((my_slot >> 6) & 1u) : 0u][(my_slot & 63u) * SUM_WORDS];
 #pragma unroll
                     for (int c = 0; c < SUM_WORDS; ++c) atomicAdd(dst + c, w[c]);
                 } else {
                     unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * SUM_WORDS;
 #pragma unroll
                     for (int c = 0; c < SUM_WORDS; ++c) atomicAdd(dst + c, w[c]);
-                }
-            } else if constexpr (MIXED && FIXED) {
-                // Q32.64 in registers: exact integer sums, whatever the order in which lanes, waves or GPUs finish samples
-                const Real ch[3] = {color.x, color.y, color.z};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    unsigned long long wa, wb;
-                    to_q32_64(ch[c], wa, wb);
-                    const uint32_t lo = sum_lo[c] + static_cast<uint32_t>(wb);
-                    sum_q[c] += wa + (lo < sum_lo[c] ? 1ull : 0ull); // the carry of the low word
-                    sum_lo[c] = lo;
                 }
             } else if constexpr (MIXED) {
                 // the sample's colour goes to its own slot; order_sum_kernel adds the slots in sample order
@@ -1382,24 +1369,8 @@ __global__ __launch_bounds__(BVH == 2 ? BVH_LDS_BLOCK_THREADS : BLOCK_THREADS) R
                 acc = acc + color;
             }
             ++s;
-            if constexpr (QUEUE) {
-                if (s >= unit_end) {
-                    // the unit is done: its sums go to the pixel's accumulators, and the lane asks for another unit
-                    if constexpr (MIXED && FIXED) {
-                        unsigned long long *dst = static_cast<unsigned long long *>(P.accum) + static_cast<int64_t>(pixel) * 6;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            atomicAdd(dst + 2 * c, sum_q[c]); atomicAdd(dst + 2 * c + 1, static_cast<unsigned long long>(sum_lo[c]));
-                            sum_q[c] = 0ull; sum_lo[c] = 0u;
-                        }
-                    }
-                    need_unit = true;
-                } else {
-                    fresh = true; // the next sample of the same pixel
-                }
-            } else {
-                fresh = true;
-            }
+            if constexpr (QUEUE) need_unit = true; // the lane asks for another unit
+            else fresh = true;
         }
         RT_PHASE(ph_end);
     }
