@@ -341,6 +341,12 @@ int32_t rt_world_create(const rt_sphere *spheres, int64_t n_spheres, const rt_ma
         // 2048 threads per CU = 8 workgroups of 256; a grid larger than what is resident is harmless
         // (late workgroups find the queue empty), a smaller one would leave CUs idle
         if (e == hipSuccess) w->resident_blocks = std::max(1, prop.multiProcessorCount) * (2048 / rtk::BLOCK_THREADS);
+        // RT_MI355X_TEST_RESIDENT_BLOCKS (a testing aid): a grid of that many workgroups, so that a small image gives
+        // every wave many work items (the tile sums' generations and late samples, the queue's refills)
+        if (const char *t = std::getenv("RT_MI355X_TEST_RESIDENT_BLOCKS")) {
+            const long v = std::strtol(t, nullptr, 10);
+            if (v >= 1 && v <= 1 << 20) w->resident_blocks = static_cast<int>(v);
+        }
     }
     for (int k = 0; k < CALL_SLOTS && e == hipSuccess; ++k) {
         w->slots[k].queue = w->queue_ring + 16 * k;

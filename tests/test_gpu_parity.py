@@ -1026,6 +1026,38 @@ def test_mixed_fixed_sums_are_exact_and_split_anywhere(rt, oracle):
     world.close()
 
 
+@pytest.mark.parametrize("blocks", [1, 3])
+@pytest.mark.parametrize("precision", [0, 3, 4])
+def test_few_waves_many_items(rt, oracle, monkeypatch, precision, blocks):
+    """A grid of one (or three) workgroups on a frame of hundreds of work items: every wave takes item after item, so the tile
+    sums go through their generations, late samples add to the accumulators directly and the queue is refilled while
+    paths are in flight -- what a full-size frame does on a full grid, at a size the oracle checks bit for bit
+    (list scan and both forms of the hierarchy)."""
+    import torch
+    monkeypatch.setenv("RT_MI355X_TEST_RESIDENT_BLOCKS", str(blocks))
+    cs, cam, sph, mat = scene(rt, "final", 96, 24)
+    w, h = cs.image_width, cs.image_height
+    # the ordered mixed mode's image is the f64 arithmetic's, sums in sample order
+    ref = oracle.render_region(w, h, (0, 0, w, h), cam, sph, mat, precision=rt.PRECISION_F64 if precision == 3 else precision, seed=21, threads=8)
+    dev = torch.device("cuda:0")
+    world = rt.World(sph, mat)          # reads the variable
+    for fetch in (rt.FETCH_AUTO, rt.FETCH_BVH, rt.FETCH_BVH_GLOBAL):
+        acc = torch.full((h, w, 3) + ((2,) if precision == 4 else ()), -1, dtype=torch.float64 if precision == 3 else torch.int64, device=dev)
+        img = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+        lin = torch.zeros(h, w, 3, dtype=torch.float64, device=dev)
+        stats = torch.zeros(rt.STATS_COUNT, dtype=torch.int64, device=dev)
+        world.render_accumulate(cam, w, h, acc.data_ptr(), seed=21, precision=precision, sphere_fetch=fetch, d_stats=stats.data_ptr())
+        world.finalize(acc.data_ptr(), w, h, 24, img.data_ptr(), precision=precision, d_linear=lin.data_ptr())
+        torch.cuda.synchronize()
+        assert int(stats[rt.STAT_SEGMENTS]) == int(ref["stats"][rt.STAT_SEGMENTS]), fetch
+        assert int(stats[rt.STAT_SAMPLES]) == w * h * 24
+        assert np.array_equal(lin.cpu().numpy(), ref["linear"]) and np.array_equal(img.cpu().numpy(), ref["image"]), fetch
+        if precision == 4:
+            words = oracle.render_fixed_words(w, h, (0, 0, w, h), cam, sph, mat, seed=21).view(np.int64)
+            assert np.array_equal(words_to_sum(acc.cpu().numpy()), words_to_sum(words)), fetch
+    world.close()
+
+
 def test_mixed_fixed_outside_the_filter_range(rt, oracle):
     """a world the filter's error bound does not cover keeps every sphere of every ray: still the f64 paths"""
     cs, sph, mat = rt.build_dev_scene(48)
