@@ -13,8 +13,9 @@
 //   atomics per pixel and item (an atomic per sample and channel costs 3.5 % of the frame, and six
 //   per sample -- the fixed-point mixed mode's two words per channel -- are more than the memory side
 //   executes).  Lanes idle only when the whole queue is empty.
-//   (Hierarchy variants of the fixed-point mixed mode, whose LDS holds the tree: a unit is one pixel's
-//   samples of the chunk; the lane adds their colours in registers and issues its atomics once per unit.)
+//   (Hierarchy variants: beside a tree staged in LDS there is room for the current item's sums only, and
+//   samples that finish after their item add to HBM directly; the f32 kernel, which lives on occupancy
+//   there, keeps its per-sample atomics.)
 //   Literal modes (f64 / f32 reference order): lane l owns pixel l of one tile and one sample
 //   chunk, sums its samples in order in a register and stores the sum.
 //   Mixed mode: f64 paths in the reference's operation order behind the f32 filter scan, whose
@@ -22,7 +23,7 @@
 //   stored to its own slot and a second kernel adds the slots in sample order, so the image is the
 //   f64 literal mode's bit for bit.
 //   Shading follows the reference line by line; the one loop in it that a wave would repeat until its unluckiest lane
-//   is through -- the rejection sampling of random_unit_vector -- is run by the wave together (first_unit_candidate).
+//   is through -- the rejection sampling of random_unit_vector -- is run by the wave together (first_unit_candidate; list scan).
 // Closest-hit scan (throughput and mixed mode)
 //   The sphere index is wave-uniform: records of sphere PAIRS {cx0,cx1, cy0,cy1, cz0,cz1, -K0,-K1},
 //   K = |c|^2 - r^2 lowered by an error margin, come through the scalar cache into SGPRs, the next group
