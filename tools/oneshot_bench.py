@@ -13,7 +13,8 @@ cam = rt.calculate_camera_render_data(cs)
 w, h = cs.image_width, cs.image_height
 img = np.zeros((h, w, 3))
 rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, precision=rt.PRECISION_F32)   # the first call loads the code object
-for precision, label in ((rt.PRECISION_F32, "f32"), (getattr(rt, "PRECISION_MIXED", None), "mixed")):
+MODES = [(rt.PRECISION_F32, "f32"), (getattr(rt, "PRECISION_MIXED", None), "mixed"), (getattr(rt, "PRECISION_MIXED_FIXED", None), "mixed-fixed")]
+for precision, label in MODES:
     if precision is None:
         continue
     rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, precision=precision)
@@ -27,11 +28,14 @@ cs, sph, mat = rt.build_final_scene(1, 1200)
 cam = rt.calculate_camera_render_data(cs)
 w, h = cs.image_width, cs.image_height
 img = np.zeros((h, w, 3))
-for k in range(3):
-    t0 = time.perf_counter()
-    st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True, precision=rt.PRECISION_F32)
-    dt = time.perf_counter() - t0
-    print(f"{name} final {w}x{h} 500 spp f32 call {k}: {dt * 1e3:.1f} ms wall, kernel {int(st[2]) / 1e6:.1f} ms")
+for precision, label in MODES:
+    if precision is None:
+        continue
+    for k in range(3):
+        t0 = time.perf_counter()
+        st = rt.render_region(img, (0, 0, w, h), cam, sph, mat, seed=1, want_stats=True, precision=precision)
+        dt = time.perf_counter() - t0
+        print(f"{name} final {w}x{h} 500 spp {label} call {k}: {dt * 1e3:.1f} ms wall, kernels {int(st[2]) / 1e6:.1f} ms")
 t0 = time.perf_counter()
 text = rt.render_ppm(w, h, cam, sph, mat, seed=1, precision=rt.PRECISION_F32)
 print(f"{name} final render_ppm: {(time.perf_counter() - t0) * 1e3:.1f} ms wall, {len(text)} bytes")
