@@ -409,7 +409,7 @@ def main():
             "value": m["value"], "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["elapsed"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": MODES[args.precision]["dtype"], "data": "synthetic",
-            "config": {"workload": f"{args.scene} scene ({len(sph)} spheres, seed 1) {w}x{h}, {total_spp} spp per frame, depth {cs.max_ray_bounces}",
+            "config": {"workload": f"{args.scene} scene ({len(sph)} spheres, scene seed {5 if args.scene == 'stress' else 1}) {w}x{h}, {total_spp} spp per frame, depth {cs.max_ray_bounces}",
                        "precision": args.precision, "parity": MODES[args.precision]["parity"], "partition": partition,
                        "total_spp": total_spp, "sphere_fetch": args.fetch, "rng": "counter, deterministic, seed 1"},
             "pct_fp32_peak": 100.0 * m["achieved"] / PEAK_FP32_TFLOPS,
