@@ -280,14 +280,17 @@ __device__ __forceinline__ int tile_row_of(const TileMap &m, int k) {
     return ((k / m.rows_per_strip) * m.strip_count + m.strip_index) * m.rows_per_strip + (k % m.rows_per_strip);
 }
 
-// Q32.32 fixed point of a non-negative f32 (truncated below 2^-32; NaN and negatives give 0).
-// Sums of these are exact and independent of the order of addition.
+// Float to u32 as the hardware converts: truncated, NaN and negatives to 0, 2^32 and above to 2^32 - 1.  (A C++ cast leaves
+// values out of range undefined, so the range tests would have to stay in front of it.)
+__device__ __forceinline__ uint32_t to_u32_saturating(float x) { uint32_t r; asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t to_u32_saturating(double x) { uint32_t r; asm("v_cvt_u32_f64_e32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// Q32.32 fixed point of a non-negative f32 (truncated below 2^-32; NaN and negatives give 0, 2^32 and above 2^64 - 2^32).
+// Sums of these are exact and independent of the order of addition.  The saturating conversions take care of NaN and
+// negatives: hi = 0, and the low word of a NaN or negative remainder is 0 as well.
 __device__ __forceinline__ unsigned long long to_q32_32(float x) {
-    if (!(x > 0.0f)) return 0ull;
-    if (x >= 4294967296.0f) return 0xFFFFFFFF00000000ull;
-    const uint32_t hi = static_cast<uint32_t>(x);
-    const float fr = x - static_cast<float>(hi);
-    const uint32_t lo = static_cast<uint32_t>(fr * 4294967296.0f);
+    const uint32_t hi = to_u32_saturating(x);
+    const float fr = x - static_cast<float>(hi); // exact: below 2^24 both are on x's grid, above it x is an integer
+    const uint32_t lo = x >= 4294967296.0f ? 0u : to_u32_saturating(fr * 4294967296.0f);
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 __device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; } // never used: the f64 queue modes stage or use Q32.64
@@ -295,16 +298,15 @@ __device__ __forceinline__ unsigned long long to_q32_32(double) { return 0ull; }
 // (units of 2^-64); x is truncated below 2^-64, NaN and negatives give 0, x >= 2^32 saturates.  Every step is exact:
 // the differences are of numbers on a common grid and below one unit of the part already taken.  Word sums of up to
 // 2^32 samples cannot overflow (a < 2^64 needs sum x < 2^32; b < 2^32 per sample).
+// Saturating conversions, no range tests: a NaN or a negative x gives 0 three times (the remainders are NaN or negative too);
+// for x >= 2^32 the first word saturates, x - (2^32 - 1) >= 1 makes the scaled remainder >= 2^32, and so on down.
 __device__ __forceinline__ void to_q32_64(double x, unsigned long long &a, unsigned long long &b) {
-    a = 0ull; b = 0ull;
-    if (!(x > 0.0)) return;
-    if (x >= 4294967296.0) { a = 0xFFFFFFFFFFFFFFFFull; b = 0xFFFFFFFFull; return; }
-    const uint32_t hi = static_cast<uint32_t>(x);                 // truncates
+    const uint32_t hi = to_u32_saturating(x);                     // truncates
     const double t1 = (x - static_cast<double>(hi)) * 4294967296.0; // in [0, 2^32)
-    const uint32_t mid = static_cast<uint32_t>(t1);
+    const uint32_t mid = to_u32_saturating(t1);
     const double t2 = (t1 - static_cast<double>(mid)) * 4294967296.0;
     a = (static_cast<unsigned long long>(hi) << 32) | mid;
-    b = static_cast<unsigned long long>(static_cast<uint32_t>(t2));
+    b = static_cast<unsigned long long>(to_u32_saturating(t2));
 }
 // The sum held by the two words, a * 2^-32 + b * 2^-64, rounded to f64 once (to nearest, ties to even): the 128-bit
 // integer T = a * 2^32 + b is normalised, its top 64 bits taken with everything below them OR-ed into the lowest (far
